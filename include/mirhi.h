@@ -1,0 +1,234 @@
+/*
+ * mirhi.h -- C ABI of the MI355X-native compute rasterizer (libmirhi.so).
+ *
+ * Drop-in boundary for the draw path of itsakeyfut/renderer-rs: every entry point below
+ * replaces one public method of the reference's `crates/rhi` object surface (the reference has
+ * no trait / plugin seam, SURVEY.md section 0.2, so the seam is the rhi structs' methods) or one step
+ * of `crates/renderer`'s draw-submit loop.  Plain pointers, sizes and #[repr(C)]-compatible
+ * structs only: a Rust `mirhi-sys` crate binds this header 1:1.
+ *
+ * Conventions
+ *   - every function returns mirhi_result; MIRHI_OK == 0; on failure
+ *     mirhi_last_error_message() returns a thread-local description whose text mirrors the
+ *     reference's RhiError payload (crates/rhi/src/error.rs:6-50).
+ *   - never aborts, never throws across the ABI.
+ *   - threading contract = the reference's: a device is shared freely (device.rs:379-380),
+ *     command buffers / recording are externally synchronised (command.rs:48-51).
+ *   - there is NO CPU fallback: creating a device without a HIP GPU fails with
+ *     MIRHI_ERR_NO_SUITABLE_GPU.
+ */
+#ifndef MIRHI_H
+#define MIRHI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRHI_ABI_VERSION 1u
+
+/* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
+typedef int32_t mirhi_result;
+enum {
+    MIRHI_OK = 0,
+    MIRHI_ERR_DEVICE = 1,           /* RhiError::VulkanError  -> any HIP runtime failure */
+    MIRHI_ERR_LOADING = 2,          /* RhiError::LoadingError -> HIP runtime / code object unavailable */
+    MIRHI_ERR_ALLOCATOR = 3,        /* RhiError::AllocatorError -> hipMalloc failure */
+    MIRHI_ERR_NO_SUITABLE_GPU = 4,  /* RhiError::NoSuitableGpu */
+    MIRHI_ERR_SHADER = 5,           /* RhiError::ShaderError  -> unknown mirhi_program */
+    MIRHI_ERR_SURFACE = 6,          /* RhiError::SurfaceError (unused: offscreen only) */
+    MIRHI_ERR_SWAPCHAIN = 7,        /* RhiError::SwapchainError (unused: offscreen only) */
+    MIRHI_ERR_INVALID_HANDLE = 8,   /* RhiError::InvalidHandle */
+    MIRHI_ERR_PIPELINE = 9,         /* RhiError::PipelineError */
+    MIRHI_ERR_LOCK_POISONED = 10,   /* RhiError::LockPoisoned */
+    MIRHI_TIMEOUT = 11,             /* RhiError::VulkanError(vk::Result::TIMEOUT) from Fence::wait */
+    MIRHI_NOT_READY = 12            /* vk::Result::NOT_READY from a fence status query */
+};
+const char* mirhi_last_error_message(void);
+const char* mirhi_result_name(mirhi_result r);
+uint32_t    mirhi_abi_version(void);
+
+/* ---- opaque handles ------------------------------------------------------------------------------- */
+typedef struct mirhi_device   mirhi_device;    /* rhi::Device        crates/rhi/src/device.rs:61-77 */
+typedef struct mirhi_buffer   mirhi_buffer;    /* rhi::Buffer        crates/rhi/src/buffer.rs:124-135 */
+typedef struct mirhi_image    mirhi_image;     /* swapchain image / DepthBuffer / texture (image.rs is a stub) */
+typedef struct mirhi_pipeline mirhi_pipeline;  /* rhi::Pipeline      crates/rhi/src/pipeline.rs:161-168 */
+typedef struct mirhi_cmd      mirhi_cmd;       /* rhi::CommandBuffer crates/rhi/src/command.rs:279-284 */
+typedef struct mirhi_fence    mirhi_fence;     /* rhi::Fence         crates/rhi/src/sync.rs:134-137 */
+
+/* ---- device: Device::new / wait_idle / Drop (device.rs:120-233,290-293,356-372) ------------------- */
+mirhi_result mirhi_device_count(int32_t* out_count);                      /* physical_device.rs:202-254 */
+mirhi_result mirhi_device_create(int32_t hip_ordinal, mirhi_device** out);
+/* same, but all work is issued on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
+mirhi_result mirhi_device_create_on_stream(int32_t hip_ordinal, void* hip_stream, mirhi_device** out);
+mirhi_result mirhi_device_wait_idle(mirhi_device* dev);
+mirhi_result mirhi_device_destroy(mirhi_device* dev);                     /* fails if children are alive */
+mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t out_len);
+/* screen-tile-row split: this device rasterizes only tile rows owned by `rank` of `world`
+ * (contiguous bands); rank 0 / world 1 = whole frame.  Gathering the bands is the caller's collective. */
+mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint32_t world);
+/* first/last+1 pixel row of the band rendered by this device for a target of `height` rows */
+mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end);
+
+/* ---- buffers: BufferUsage + Buffer (buffer.rs:47-112,149-293,345-417) ------------------------------ */
+typedef enum {
+    MIRHI_BUFFER_VERTEX = 0, MIRHI_BUFFER_INDEX = 1, MIRHI_BUFFER_UNIFORM = 2,
+    MIRHI_BUFFER_STORAGE = 3, MIRHI_BUFFER_STAGING = 4, MIRHI_BUFFER_INDIRECT = 5
+} mirhi_buffer_usage;
+mirhi_result mirhi_buffer_create(mirhi_device* dev, mirhi_buffer_usage usage, uint64_t size, mirhi_buffer** out); /* Buffer::new :149 (size 0 -> InvalidHandle) */
+mirhi_result mirhi_buffer_create_with_data(mirhi_device* dev, mirhi_buffer_usage usage, const void* data, uint64_t len, mirhi_buffer** out); /* Buffer::new_with_data :227 */
+mirhi_result mirhi_buffer_write(mirhi_buffer* buf, uint64_t offset, const void* data, uint64_t len);   /* Buffer::write_data :247 (bounds-checked; Storage/Indirect are "not mapped") */
+mirhi_result mirhi_buffer_upload(mirhi_buffer* buf, const void* data, uint64_t len);                    /* Buffer::upload :291 */
+mirhi_result mirhi_buffer_upload_via_staging(mirhi_buffer* buf, const void* data, uint64_t len);        /* Buffer::upload_via_staging :345 */
+/* wrap memory that is already resident in HBM (e.g. a torch tensor); not freed on destroy */
+mirhi_result mirhi_buffer_wrap_device_memory(mirhi_device* dev, mirhi_buffer_usage usage, void* device_ptr, uint64_t size, mirhi_buffer** out);
+mirhi_result mirhi_buffer_read(mirhi_buffer* buf, uint64_t offset, void* dst, uint64_t len);           /* added: reference has no readback */
+uint64_t     mirhi_buffer_size(const mirhi_buffer* buf);                                                /* Buffer::size :409 */
+int32_t      mirhi_buffer_usage_of(const mirhi_buffer* buf);                                            /* Buffer::usage :415 */
+void*        mirhi_buffer_device_ptr(const mirhi_buffer* buf);                                          /* Buffer::handle :403 */
+mirhi_result mirhi_buffer_destroy(mirhi_buffer* buf);
+
+/* ---- images: colour targets, DepthBuffer, textures -------------------------------------------------
+ * formats: swapchain.rs:561-570 (B8G8R8A8_SRGB), depth_buffer.rs:48 (D32_SFLOAT); RGBA32F is the
+ * parity target (linear, pre-quantisation); RGBA8_UNORM is the sampled-texture format. */
+typedef enum {
+    MIRHI_FORMAT_UNDEFINED = 0,
+    MIRHI_FORMAT_B8G8R8A8_SRGB = 1,
+    MIRHI_FORMAT_R32G32B32A32_SFLOAT = 2,
+    MIRHI_FORMAT_D32_SFLOAT = 3,
+    MIRHI_FORMAT_R8G8B8A8_UNORM = 4,
+    MIRHI_FORMAT_R32_UINT = 5       /* debug/parity: winning primitive id per pixel */
+} mirhi_format;
+mirhi_result mirhi_image_create(mirhi_device* dev, uint32_t width, uint32_t height, mirhi_format format, mirhi_image** out); /* DepthBuffer::new depth_buffer.rs:117-127 (0 size -> error) */
+mirhi_result mirhi_image_wrap_device_memory(mirhi_device* dev, uint32_t width, uint32_t height, mirhi_format format, void* device_ptr, mirhi_image** out);
+mirhi_result mirhi_image_upload(mirhi_image* img, const void* src, uint64_t len);
+mirhi_result mirhi_image_read(mirhi_image* img, void* dst, uint64_t len);   /* added: swapchain images have no readback (swapchain.rs:255) */
+uint32_t     mirhi_image_width(const mirhi_image* img);
+uint32_t     mirhi_image_height(const mirhi_image* img);
+int32_t      mirhi_image_format(const mirhi_image* img);
+uint64_t     mirhi_image_size_bytes(const mirhi_image* img);
+void*        mirhi_image_device_ptr(const mirhi_image* img);
+mirhi_result mirhi_image_destroy(mirhi_image* img);
+
+/* ---- pipeline: GraphicsPipelineBuilder (pipeline.rs:590-1059) -------------------------------------- */
+typedef enum {   /* replaces Shader::from_spirv_file (shader.rs:244-330): precompiled .hip programs */
+    MIRHI_PROGRAM_NONE = -1,
+    MIRHI_PROGRAM_TRIANGLE = 0,     /* vertex/triangle.hlsl + pixel/triangle.hlsl */
+    MIRHI_PROGRAM_MODEL = 1,        /* vertex/model.hlsl + pixel/model.hlsl (hard-coded fallback light/material) */
+    MIRHI_PROGRAM_MODEL_FULL = 2    /* vertex/model.hlsl + pixel/model_full.hlsl + lights.hlsli */
+} mirhi_program;
+typedef enum { MIRHI_TOPOLOGY_POINT_LIST = 0, MIRHI_TOPOLOGY_LINE_LIST = 1, MIRHI_TOPOLOGY_LINE_STRIP = 2,
+               MIRHI_TOPOLOGY_TRIANGLE_LIST = 3, MIRHI_TOPOLOGY_TRIANGLE_STRIP = 4, MIRHI_TOPOLOGY_TRIANGLE_FAN = 5 } mirhi_topology;   /* pipeline.rs:274-300 */
+typedef enum { MIRHI_POLYGON_FILL = 0, MIRHI_POLYGON_LINE = 1, MIRHI_POLYGON_POINT = 2 } mirhi_polygon_mode;                          /* :306-325 */
+typedef enum { MIRHI_CULL_NONE = 0, MIRHI_CULL_FRONT = 1, MIRHI_CULL_BACK = 2, MIRHI_CULL_FRONT_AND_BACK = 3 } mirhi_cull_mode;        /* :329-351 */
+typedef enum { MIRHI_FRONT_FACE_COUNTER_CLOCKWISE = 0, MIRHI_FRONT_FACE_CLOCKWISE = 1 } mirhi_front_face;                              /* :355-371 */
+typedef enum { MIRHI_COMPARE_NEVER = 0, MIRHI_COMPARE_LESS = 1, MIRHI_COMPARE_EQUAL = 2, MIRHI_COMPARE_LESS_OR_EQUAL = 3,
+               MIRHI_COMPARE_GREATER = 4, MIRHI_COMPARE_NOT_EQUAL = 5, MIRHI_COMPARE_GREATER_OR_EQUAL = 6, MIRHI_COMPARE_ALWAYS = 7 } mirhi_compare_op; /* :375-409 */
+
+typedef struct {
+    int32_t  vertex_program;            /* builder.vertex_shader();   MIRHI_PROGRAM_NONE -> "Vertex shader is required" */
+    int32_t  fragment_program;          /* builder.fragment_shader(); MIRHI_PROGRAM_NONE -> "Fragment shader is required" */
+    uint32_t vertex_stride;             /* vertex_binding(): 24 TriangleVertex / 48 Vertex (vertex.rs:35-41,130-136) */
+    uint32_t attribute_count;           /* vertex_attributes(): byte offsets by location (vertex.rs:44-61,139-170) */
+    uint32_t attribute_offsets[4];
+    int32_t  topology;                  /* default TRIANGLE_LIST   pipeline.rs:655 */
+    int32_t  polygon_mode;              /* default FILL            :659 */
+    int32_t  cull_mode;                 /* default BACK            :660 */
+    int32_t  front_face;                /* default COUNTER_CLOCKWISE :661 */
+    uint32_t depth_clamp_enable;        /* default 0               :662 */
+    uint32_t rasterizer_discard_enable; /* default 0               :663 */
+    uint32_t depth_bias_enable;         /* default 0               :664 */
+    uint32_t rasterization_samples;     /* default 1               :671 */
+    uint32_t depth_test_enable;         /* default 1               :676 */
+    uint32_t depth_write_enable;        /* default 1               :677 */
+    int32_t  depth_compare_op;          /* default LESS            :678 */
+    uint32_t blend_enable;              /* default 0               :499-512 */
+    uint32_t blend_attachment_count;    /* default 0 = one default attachment per colour format :1007-1018 */
+    uint32_t color_attachment_count;    /* default 0 -> "At least one color attachment format is required" */
+    int32_t  color_attachment_formats[4];
+    int32_t  depth_attachment_format;   /* default UNDEFINED (None) :690 */
+} mirhi_pipeline_desc;
+void         mirhi_pipeline_desc_default(mirhi_pipeline_desc* desc);                      /* GraphicsPipelineBuilder::new :645-698 */
+mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pipeline_desc* desc, mirhi_pipeline** out); /* build :918-1057 */
+mirhi_result mirhi_pipeline_destroy(mirhi_pipeline* p);
+
+/* ---- command recording: CommandBuffer (command.rs:297-628) ------------------------------------------ */
+typedef enum { MIRHI_LOAD_OP_LOAD = 0, MIRHI_LOAD_OP_CLEAR = 1, MIRHI_LOAD_OP_DONT_CARE = 2 } mirhi_load_op;
+typedef enum { MIRHI_STORE_OP_STORE = 0, MIRHI_STORE_OP_DONT_CARE = 1 } mirhi_store_op;
+typedef enum { MIRHI_INDEX_UINT16 = 0, MIRHI_INDEX_UINT32 = 1 } mirhi_index_type;
+
+typedef struct {     /* RenderingConfig / ColorAttachment / DepthAttachment (rendering.rs:65-115,319-370,680-726) */
+    mirhi_image* color_image;        /* required */
+    int32_t      color_load_op;      /* default CLEAR  rendering.rs:106 */
+    int32_t      color_store_op;     /* default STORE  :107 */
+    float        clear_color[4];     /* default (0,0,0,1) :108-112 */
+    mirhi_image* depth_image;        /* optional; NULL + a depth-testing pipeline keeps depth on chip only */
+    int32_t      depth_load_op;      /* default CLEAR  :360 */
+    int32_t      depth_store_op;     /* default DONT_CARE :361 */
+    float        clear_depth;        /* default 1.0    :362-366 */
+    int32_t      render_area[4];     /* x, y, width, height; width==0 -> full extent (rendering.rs:713-726) */
+    mirhi_image* prim_id_image;      /* optional R32_UINT: winning global primitive id (parity instrumentation) */
+} mirhi_rendering_info;
+void mirhi_rendering_info_default(mirhi_rendering_info* info);
+
+typedef struct { float x, y, width, height, min_depth, max_depth; } mirhi_viewport;  /* vk::Viewport, renderer.rs:504-512 */
+typedef struct { int32_t x, y; uint32_t width, height; } mirhi_rect2d;              /* vk::Rect2D,   renderer.rs:514-518 */
+
+/* descriptor stand-in: register slots of shaders/hlsl (model.hlsl:5-19, model_full.hlsl:27-50) */
+typedef enum {
+    MIRHI_SLOT_CAMERA = 0,        /* b0 CameraData 208 B */
+    MIRHI_SLOT_OBJECT = 1,        /* b1 ObjectData 128 B */
+    MIRHI_SLOT_LIGHTS = 2,        /* b2 LightUBO 48 B */
+    MIRHI_SLOT_MATERIAL = 3,      /* b3 MaterialData 32 B */
+    MIRHI_SLOT_POINT_LIGHTS = 4,  /* t0,space1 StructuredBuffer<PointLight> */
+    MIRHI_SLOT_SPOT_LIGHTS = 5,   /* t1,space1 StructuredBuffer<SpotLight> */
+    MIRHI_SLOT_COUNT = 6
+} mirhi_uniform_slot;
+typedef enum { MIRHI_TEXTURE_ALBEDO = 0 /* t0 */, MIRHI_TEXTURE_NORMAL = 1 /* t1 */, MIRHI_TEXTURE_COUNT = 2 } mirhi_texture_slot;
+
+mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out);                 /* CommandPool::new + CommandBuffer::new :89,:297 */
+mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd);
+mirhi_result mirhi_cmd_begin(mirhi_cmd* cmd);                                       /* begin :333 (ONE_TIME_SUBMIT) */
+mirhi_result mirhi_cmd_begin_reusable(mirhi_cmd* cmd);                              /* begin_reusable :353 */
+mirhi_result mirhi_cmd_end(mirhi_cmd* cmd);                                         /* end :372 */
+mirhi_result mirhi_cmd_reset(mirhi_cmd* cmd);                                       /* reset :387 */
+mirhi_result mirhi_cmd_begin_rendering(mirhi_cmd* cmd, const mirhi_rendering_info* info);  /* begin_rendering :408 */
+mirhi_result mirhi_cmd_end_rendering(mirhi_cmd* cmd);                               /* end_rendering :417 */
+mirhi_result mirhi_cmd_bind_pipeline(mirhi_cmd* cmd, mirhi_pipeline* pipeline);     /* bind_pipeline :433 */
+mirhi_result mirhi_cmd_bind_vertex_buffers(mirhi_cmd* cmd, uint32_t first_binding, uint32_t count, mirhi_buffer* const* buffers, const uint64_t* offsets); /* :448 */
+mirhi_result mirhi_cmd_bind_index_buffer(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, mirhi_index_type type); /* :471 */
+mirhi_result mirhi_cmd_bind_uniform(mirhi_cmd* cmd, mirhi_uniform_slot slot, mirhi_buffer* buffer, uint64_t offset, uint64_t range); /* bind_descriptor_sets :493 + descriptor.rs:390-409 buffer_info */
+mirhi_result mirhi_cmd_bind_texture(mirhi_cmd* cmd, mirhi_texture_slot slot, mirhi_image* image);   /* descriptor.rs:411-420 image_info */
+mirhi_result mirhi_cmd_set_viewport(mirhi_cmd* cmd, const mirhi_viewport* viewport);  /* set_viewport :522 */
+mirhi_result mirhi_cmd_set_scissor(mirhi_cmd* cmd, const mirhi_rect2d* scissor);      /* set_scissor :549 */
+mirhi_result mirhi_cmd_draw(mirhi_cmd* cmd, uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance); /* draw :583 */
+mirhi_result mirhi_cmd_draw_indexed(mirhi_cmd* cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance); /* draw_indexed :610 */
+
+/* ---- submit + sync: vkQueueSubmit (renderer.rs:407-424, frame_manager.rs:439-462), Fence (sync.rs:168-298) */
+mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence /* may be NULL */);
+mirhi_result mirhi_fence_create(mirhi_device* dev, uint32_t signaled, mirhi_fence** out);   /* Fence::new :168 */
+mirhi_result mirhi_fence_wait(mirhi_fence* fence, uint64_t timeout_ns);                     /* Fence::wait :228 (UINT64_MAX = forever) */
+mirhi_result mirhi_fence_reset(mirhi_fence* fence);                                         /* Fence::reset :264 */
+mirhi_result mirhi_fence_status(mirhi_fence* fence);    /* MIRHI_OK = signaled, MIRHI_NOT_READY = unsignaled; Fence::is_signaled :294 */
+mirhi_result mirhi_fence_destroy(mirhi_fence* fence);
+
+/* ---- measurement: per-kernel device time from HIP events on the submit stream ---------- */
+typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_COUNT = 2 } mirhi_kernel_id;
+mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);   /* brackets each kernel with hipEvents */
+/* accumulated since the last reset; waits for outstanding events */
+mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches);
+mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev);
+typedef struct {
+    uint64_t frames_submitted;      /* rendering scopes executed */
+    uint64_t triangles_submitted;   /* input triangles over those scopes */
+    uint64_t workspace_bytes;       /* HBM held for bins / records */
+    uint32_t last_big_list;         /* triangles that took the large/overflow list in the last finished scope */
+    uint32_t last_status;           /* device status word of the last finished scope (0 = ok) */
+} mirhi_device_stats;
+mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRHI_H */

@@ -255,7 +255,7 @@ static int setup_triangle(const oracle_pass* pass, const oracle_draw* d, uint32_
         float xs = (c[i].x * iw) * hw + cx;                      /* Vulkan viewport transform */
         float ys = (c[i].y * iw) * hh + cy;
         float zs = (c[i].z * iw) * dscale + dmin;
-        if (!(fabsf(xs) <= 16384.0f) || !(fabsf(ys) <= 16384.0f)) return 0;
+        if (!(fabsf(xs) <= 16383.0f) || !(fabsf(ys) <= 16383.0f)) return 0;
         X[i] = (int32_t)rintf(xs * 256.0f);                      /* 8 sub-pixel bits, round-half-even */
         Y[i] = (int32_t)rintf(ys * 256.0f);
         z[i] = zs;

@@ -1,0 +1,55 @@
+"""Builds libmirhi.so (HIP kernels + C ABI) for gfx950 with hipcc. In-tree output: renderer-rs_amd/libmirhi.so."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmirhi.so")
+SOURCES = ["mirhi_kernels.hip", "mirhi_api.hip"]
+HEADERS = ["mirhi_device.h", "mirhi_launch.h", os.path.join("..", "..", "include", "mirhi.h")]
+# -ffp-contract=off: coverage/depth arithmetic must match the oracle bit for bit
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X kernels cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(CSRC, s + ".o")
+        cmd = [hipcc(), *FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
+    print(LIB)

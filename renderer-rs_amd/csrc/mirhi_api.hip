@@ -1,0 +1,1043 @@
+// mirhi_api.hip -- implementation of the C ABI declared in include/mirhi.h.
+//
+// Host-only logic: object lifetimes, validation with the reference's error behaviour
+// (crates/rhi/src/{buffer,pipeline,command,sync}.rs), translation of a recorded command buffer
+// into kernel launches on a HIP stream (crates/renderer/src/renderer.rs:452-557,
+// frame_manager.rs:299-539).  No rasterization arithmetic lives here and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mirhi.h"
+#include "mirhi_device.h"
+#include "mirhi_launch.h"
+
+using namespace mirhi;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static mirhi_result fail(mirhi_result code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+static mirhi_result hip_fail(hipError_t e, const char* what) {
+    const mirhi_result code = (e == hipErrorOutOfMemory) ? MIRHI_ERR_ALLOCATOR : MIRHI_ERR_DEVICE;
+    return fail(code, "%s: %s (%s)", code == MIRHI_ERR_ALLOCATOR ? "Allocator error" : "Vulkan error", hipGetErrorString(e), what);
+}
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e__ = (expr);                                   \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);        \
+    } while (0)
+#define NULL_CHECK(p, name)                                        \
+    do {                                                           \
+        if (!(p)) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: %s is null", name); \
+    } while (0)
+
+extern "C" const char* mirhi_last_error_message(void) { return g_last_error.c_str(); }
+extern "C" uint32_t mirhi_abi_version(void) { return MIRHI_ABI_VERSION; }
+extern "C" const char* mirhi_result_name(mirhi_result r) {
+    switch (r) {
+        case MIRHI_OK: return "Ok";
+        case MIRHI_ERR_DEVICE: return "VulkanError";
+        case MIRHI_ERR_LOADING: return "LoadingError";
+        case MIRHI_ERR_ALLOCATOR: return "AllocatorError";
+        case MIRHI_ERR_NO_SUITABLE_GPU: return "NoSuitableGpu";
+        case MIRHI_ERR_SHADER: return "ShaderError";
+        case MIRHI_ERR_SURFACE: return "SurfaceError";
+        case MIRHI_ERR_SWAPCHAIN: return "SwapchainError";
+        case MIRHI_ERR_INVALID_HANDLE: return "InvalidHandle";
+        case MIRHI_ERR_PIPELINE: return "PipelineError";
+        case MIRHI_ERR_LOCK_POISONED: return "LockPoisoned";
+        case MIRHI_TIMEOUT: return "Timeout";
+        case MIRHI_NOT_READY: return "NotReady";
+        default: return "Unknown";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------------
+struct EventPair { hipEvent_t a, b; };
+
+struct mirhi_device {
+    int ordinal = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::atomic<int> children{0};
+    uint32_t split_rank = 0, split_world = 1;
+    bool profiling = false;
+    std::mutex mu;
+    std::vector<EventPair> pending[MIRHI_KERNEL_COUNT];
+    std::vector<EventPair> free_events;
+    double total_ms[MIRHI_KERNEL_COUNT] = {0, 0};
+    uint64_t launches[MIRHI_KERNEL_COUNT] = {0, 0};
+    mirhi_device_stats stats{};
+    char name[256] = {0};
+};
+
+struct mirhi_buffer {
+    mirhi_device* dev;
+    mirhi_buffer_usage usage;
+    uint64_t size;
+    uint8_t* ptr;
+    bool owned;
+};
+
+struct mirhi_image {
+    mirhi_device* dev;
+    uint32_t width, height;
+    mirhi_format format;
+    uint8_t* ptr;
+    bool owned;
+};
+
+struct mirhi_pipeline {
+    mirhi_device* dev;
+    mirhi_pipeline_desc desc;
+};
+
+struct RecordedPass {
+    mirhi_rendering_info info;
+    std::vector<DrawDesc> draws;
+    uint32_t total_tris = 0;
+    bool key_set = false;
+    uint32_t depth_test = 0, depth_compare = 0;
+    int32_t area[4] = {0, 0, 0, 0};
+};
+
+struct Workspace {
+    DrawDesc* draws = nullptr; size_t draws_cap = 0;
+    TileRec* bin_recs = nullptr; size_t bin_recs_bytes = 0;
+    uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
+    BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
+    uint32_t* status_host = nullptr;                             // pinned: [status, big_count]
+    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes; }
+};
+
+enum CmdState { CMD_INITIAL = 0, CMD_RECORDING = 1, CMD_EXECUTABLE = 2 };
+
+struct mirhi_cmd {
+    mirhi_device* dev;
+    CmdState state = CMD_INITIAL;
+    bool one_time = true;
+    bool in_rendering = false;
+    std::vector<RecordedPass> passes;
+    // current bindings (dynamic state + descriptors)
+    mirhi_pipeline* pipeline = nullptr;
+    mirhi_buffer* vb = nullptr; uint64_t vb_offset = 0;
+    mirhi_buffer* ib = nullptr; uint64_t ib_offset = 0; mirhi_index_type ib_type = MIRHI_INDEX_UINT32;
+    struct { mirhi_buffer* buf; uint64_t offset, range; } uniforms[MIRHI_SLOT_COUNT] = {};
+    mirhi_image* textures[MIRHI_TEXTURE_COUNT] = {nullptr, nullptr};
+    bool has_viewport = false, has_scissor = false;
+    mirhi_viewport viewport{};
+    mirhi_rect2d scissor{};
+    // device-side plan, built at end()
+    Workspace ws;
+    std::vector<PassParams> plan;
+    uint64_t plan_tris = 0;
+};
+
+struct mirhi_fence {
+    mirhi_device* dev;
+    hipEvent_t event = nullptr;
+    bool signaled = false;      // host-visible signaled state
+    bool pending = false;       // an event record is outstanding
+    std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
+};
+
+static uint32_t format_bpp(mirhi_format f) {
+    switch (f) {
+        case MIRHI_FORMAT_B8G8R8A8_SRGB: case MIRHI_FORMAT_D32_SFLOAT: case MIRHI_FORMAT_R8G8B8A8_UNORM:
+        case MIRHI_FORMAT_R32_UINT: return 4;
+        case MIRHI_FORMAT_R32G32B32A32_SFLOAT: return 16;
+        default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------------------
+extern "C" mirhi_result mirhi_device_count(int32_t* out_count) {
+    NULL_CHECK(out_count, "out_count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out_count = 0; (void)hipGetLastError(); return MIRHI_OK; }
+    *out_count = n;
+    return MIRHI_OK;
+}
+
+static mirhi_result device_create_common(int32_t ordinal, void* stream, bool external, mirhi_device** out) {
+    NULL_CHECK(out, "out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(MIRHI_ERR_NO_SUITABLE_GPU, "No suitable GPU found"); }
+    if (ordinal < 0 || ordinal >= n) return fail(MIRHI_ERR_NO_SUITABLE_GPU, "No suitable GPU found (ordinal %d of %d)", ordinal, n);
+    HIP_TRY(hipSetDevice(ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MIRHI_ERR_NO_SUITABLE_GPU, "No suitable GPU found (device %d is %s, kernels are built for gfx950)", ordinal, prop.gcnArchName);
+    mirhi_device* d = new (std::nothrow) mirhi_device();
+    if (!d) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    d->ordinal = ordinal;
+    snprintf(d->name, sizeof d->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (external) { d->stream = (hipStream_t)stream; d->owns_stream = false; }
+    else {
+        hipError_t se = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete d; return hip_fail(se, "hipStreamCreateWithFlags"); }
+        d->owns_stream = true;
+    }
+    *out = d;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_create(int32_t ordinal, mirhi_device** out) { return device_create_common(ordinal, nullptr, false, out); }
+extern "C" mirhi_result mirhi_device_create_on_stream(int32_t ordinal, void* stream, mirhi_device** out) { return device_create_common(ordinal, stream, true, out); }
+
+extern "C" mirhi_result mirhi_device_wait_idle(mirhi_device* dev) {
+    NULL_CHECK(dev, "device");
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
+    NULL_CHECK(dev, "device");
+    if (dev->children.load() != 0)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: device still has %d live child objects", dev->children.load());
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipStreamSynchronize(dev->stream);
+    for (auto& v : dev->pending) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : dev->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (dev->owns_stream) (void)hipStreamDestroy(dev->stream);
+    delete dev;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t out_len) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    if (out_len == 0) return MIRHI_OK;
+    snprintf(out, out_len, "%s", dev->name);
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint32_t world) {
+    NULL_CHECK(dev, "device");
+    if (world == 0 || rank >= world) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: tile split rank %u of %u", rank, world);
+    dev->split_rank = rank; dev->split_world = world;
+    return MIRHI_OK;
+}
+static void band_tile_rows(const mirhi_device* dev, uint32_t tiles_y, uint32_t* r0, uint32_t* r1) {
+    const uint32_t per = (tiles_y + dev->split_world - 1) / dev->split_world;   // contiguous bands, last rank short
+    uint32_t b = dev->split_rank * per, e = b + per;
+    if (b > tiles_y) b = tiles_y;
+    if (e > tiles_y) e = tiles_y;
+    *r0 = b; *r1 = e;
+}
+extern "C" mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(row_begin, "row_begin"); NULL_CHECK(row_end, "row_end");
+    const uint32_t tiles_y = (height + TILE - 1) / TILE;
+    uint32_t r0, r1;
+    band_tile_rows(dev, tiles_y, &r0, &r1);
+    uint32_t p0 = r0 * TILE, p1 = r1 * TILE;
+    if (p0 > height) p0 = height;
+    if (p1 > height) p1 = height;
+    *row_begin = p0; *row_end = p1;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buffers (buffer.rs)
+// ------------------------------------------------------------------------------------------------
+static const char* usage_name(mirhi_buffer_usage u) {
+    static const char* names[] = {"vertex", "index", "uniform", "storage", "staging", "indirect"};
+    return (u >= 0 && u <= 5) ? names[u] : "unknown";
+}
+static bool usage_host_visible(mirhi_buffer_usage u) {   // BufferUsage::memory_location buffer.rs:86-100
+    return u == MIRHI_BUFFER_VERTEX || u == MIRHI_BUFFER_INDEX || u == MIRHI_BUFFER_UNIFORM || u == MIRHI_BUFFER_STAGING;
+}
+
+extern "C" mirhi_result mirhi_buffer_create(mirhi_device* dev, mirhi_buffer_usage usage, uint64_t size, mirhi_buffer** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    *out = nullptr;
+    if ((int)usage < 0 || (int)usage > 5) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown buffer usage %d", (int)usage);
+    if (size == 0) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer size must be greater than 0");   // buffer.rs:150-154
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size + 255) & ~(uint64_t)255);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc(%llu) for %s buffer: %s", (unsigned long long)size, usage_name(usage), hipGetErrorString(e)); }
+    mirhi_buffer* b = new (std::nothrow) mirhi_buffer{dev, usage, size, (uint8_t*)p, true};
+    if (!b) { (void)hipFree(p); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed"); }
+    dev->children++;
+    *out = b;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_buffer_write(mirhi_buffer* buf, uint64_t offset, const void* data, uint64_t len) {
+    NULL_CHECK(buf, "buffer");
+    if (len == 0) return MIRHI_OK;                                                        // buffer.rs:248-250
+    NULL_CHECK(data, "data");
+    if (offset + len > buf->size || offset + len < offset)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Write exceeds buffer size: offset %llu + data %llu > buffer %llu",
+                    (unsigned long long)offset, (unsigned long long)len, (unsigned long long)buf->size);   // buffer.rs:252-260
+    if (!usage_host_visible(buf->usage))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer memory is not mapped");              // buffer.rs:266-268
+    HIP_TRY(hipSetDevice(buf->dev->ordinal));
+    // host-coherent write semantics: ordered after previously submitted work, visible to later submits
+    HIP_TRY(hipMemcpyAsync(buf->ptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
+    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_buffer_upload(mirhi_buffer* buf, const void* data, uint64_t len) { return mirhi_buffer_write(buf, 0, data, len); }
+extern "C" mirhi_result mirhi_buffer_upload_via_staging(mirhi_buffer* buf, const void* data, uint64_t len) {
+    NULL_CHECK(buf, "buffer");
+    if (len == 0) return MIRHI_OK;
+    NULL_CHECK(data, "data");
+    if (len > buf->size)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Upload exceeds buffer size: data %llu > buffer %llu", (unsigned long long)len, (unsigned long long)buf->size);
+    HIP_TRY(hipSetDevice(buf->dev->ordinal));
+    HIP_TRY(hipMemcpyAsync(buf->ptr, data, len, hipMemcpyHostToDevice, buf->dev->stream));
+    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_buffer_create_with_data(mirhi_device* dev, mirhi_buffer_usage usage, const void* data, uint64_t len, mirhi_buffer** out) {
+    mirhi_result r = mirhi_buffer_create(dev, usage, len, out);                           // buffer.rs:227-231
+    if (r != MIRHI_OK) return r;
+    r = mirhi_buffer_write(*out, 0, data, len);
+    if (r != MIRHI_OK) { std::string keep = g_last_error; mirhi_buffer_destroy(*out); *out = nullptr; g_last_error = keep; }
+    return r;
+}
+extern "C" mirhi_result mirhi_buffer_wrap_device_memory(mirhi_device* dev, mirhi_buffer_usage usage, void* device_ptr, uint64_t size, mirhi_buffer** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    *out = nullptr;
+    if (size == 0 || !device_ptr) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer size must be greater than 0");
+    mirhi_buffer* b = new (std::nothrow) mirhi_buffer{dev, usage, size, (uint8_t*)device_ptr, false};
+    if (!b) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    dev->children++;
+    *out = b;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_buffer_read(mirhi_buffer* buf, uint64_t offset, void* dst, uint64_t len) {
+    NULL_CHECK(buf, "buffer");
+    if (len == 0) return MIRHI_OK;
+    NULL_CHECK(dst, "dst");
+    if (offset + len > buf->size || offset + len < offset)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Read exceeds buffer size: offset %llu + len %llu > buffer %llu",
+                    (unsigned long long)offset, (unsigned long long)len, (unsigned long long)buf->size);
+    HIP_TRY(hipSetDevice(buf->dev->ordinal));
+    HIP_TRY(hipMemcpyAsync(dst, buf->ptr + offset, len, hipMemcpyDeviceToHost, buf->dev->stream));
+    HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+    return MIRHI_OK;
+}
+extern "C" uint64_t mirhi_buffer_size(const mirhi_buffer* buf) { return buf ? buf->size : 0; }
+extern "C" int32_t mirhi_buffer_usage_of(const mirhi_buffer* buf) { return buf ? (int32_t)buf->usage : -1; }
+extern "C" void* mirhi_buffer_device_ptr(const mirhi_buffer* buf) { return buf ? buf->ptr : nullptr; }
+extern "C" mirhi_result mirhi_buffer_destroy(mirhi_buffer* buf) {
+    NULL_CHECK(buf, "buffer");
+    (void)hipSetDevice(buf->dev->ordinal);
+    if (buf->owned) { (void)hipStreamSynchronize(buf->dev->stream); (void)hipFree(buf->ptr); }
+    buf->dev->children--;
+    delete buf;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// images
+// ------------------------------------------------------------------------------------------------
+static mirhi_result image_common(mirhi_device* dev, uint32_t w, uint32_t h, mirhi_format f, void* ext, mirhi_image** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    *out = nullptr;
+    if (w == 0 || h == 0)   // depth_buffer.rs:118-127
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Image dimensions must be greater than 0 (got %ux%u)", w, h);
+    if (w > 16384 || h > 16384) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Image dimensions exceed 16384 (got %ux%u)", w, h);
+    const uint32_t bpp = format_bpp(f);
+    if (bpp == 0) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unsupported image format %d", (int)f);
+    void* p = ext;
+    if (!ext) {
+        HIP_TRY(hipSetDevice(dev->ordinal));
+        hipError_t e = hipMalloc(&p, (size_t)w * h * bpp);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc for %ux%u image: %s", w, h, hipGetErrorString(e)); }
+    }
+    mirhi_image* img = new (std::nothrow) mirhi_image{dev, w, h, f, (uint8_t*)p, ext == nullptr};
+    if (!img) { if (!ext) (void)hipFree(p); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed"); }
+    dev->children++;
+    *out = img;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_image_create(mirhi_device* dev, uint32_t w, uint32_t h, mirhi_format f, mirhi_image** out) { return image_common(dev, w, h, f, nullptr, out); }
+extern "C" mirhi_result mirhi_image_wrap_device_memory(mirhi_device* dev, uint32_t w, uint32_t h, mirhi_format f, void* ptr, mirhi_image** out) {
+    if (!ptr) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: device_ptr is null");
+    return image_common(dev, w, h, f, ptr, out);
+}
+extern "C" uint32_t mirhi_image_width(const mirhi_image* img) { return img ? img->width : 0; }
+extern "C" uint32_t mirhi_image_height(const mirhi_image* img) { return img ? img->height : 0; }
+extern "C" int32_t mirhi_image_format(const mirhi_image* img) { return img ? (int32_t)img->format : 0; }
+extern "C" uint64_t mirhi_image_size_bytes(const mirhi_image* img) { return img ? (uint64_t)img->width * img->height * format_bpp(img->format) : 0; }
+extern "C" void* mirhi_image_device_ptr(const mirhi_image* img) { return img ? img->ptr : nullptr; }
+extern "C" mirhi_result mirhi_image_upload(mirhi_image* img, const void* src, uint64_t len) {
+    NULL_CHECK(img, "image"); NULL_CHECK(src, "src");
+    if (len != mirhi_image_size_bytes(img))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: image upload size %llu != image size %llu", (unsigned long long)len, (unsigned long long)mirhi_image_size_bytes(img));
+    HIP_TRY(hipSetDevice(img->dev->ordinal));
+    HIP_TRY(hipMemcpyAsync(img->ptr, src, len, hipMemcpyHostToDevice, img->dev->stream));
+    HIP_TRY(hipStreamSynchronize(img->dev->stream));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_image_read(mirhi_image* img, void* dst, uint64_t len) {
+    NULL_CHECK(img, "image"); NULL_CHECK(dst, "dst");
+    if (len != mirhi_image_size_bytes(img))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: image read size %llu != image size %llu", (unsigned long long)len, (unsigned long long)mirhi_image_size_bytes(img));
+    HIP_TRY(hipSetDevice(img->dev->ordinal));
+    HIP_TRY(hipMemcpyAsync(dst, img->ptr, len, hipMemcpyDeviceToHost, img->dev->stream));
+    HIP_TRY(hipStreamSynchronize(img->dev->stream));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_image_destroy(mirhi_image* img) {
+    NULL_CHECK(img, "image");
+    (void)hipSetDevice(img->dev->ordinal);
+    if (img->owned) { (void)hipStreamSynchronize(img->dev->stream); (void)hipFree(img->ptr); }
+    img->dev->children--;
+    delete img;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipeline (pipeline.rs:645-698 defaults, :918-952 validation)
+// ------------------------------------------------------------------------------------------------
+extern "C" void mirhi_pipeline_desc_default(mirhi_pipeline_desc* d) {
+    if (!d) return;
+    memset(d, 0, sizeof *d);
+    d->vertex_program = MIRHI_PROGRAM_NONE;
+    d->fragment_program = MIRHI_PROGRAM_NONE;
+    d->topology = MIRHI_TOPOLOGY_TRIANGLE_LIST;
+    d->polygon_mode = MIRHI_POLYGON_FILL;
+    d->cull_mode = MIRHI_CULL_BACK;
+    d->front_face = MIRHI_FRONT_FACE_COUNTER_CLOCKWISE;
+    d->rasterization_samples = 1;
+    d->depth_test_enable = 1;
+    d->depth_write_enable = 1;
+    d->depth_compare_op = MIRHI_COMPARE_LESS;
+    d->depth_attachment_format = MIRHI_FORMAT_UNDEFINED;
+}
+
+extern "C" mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pipeline_desc* d, mirhi_pipeline** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(d, "desc"); NULL_CHECK(out, "out");
+    *out = nullptr;
+    // --- the reference's own validation, same order and text (pipeline.rs:920-952) ---
+    if (d->vertex_program == MIRHI_PROGRAM_NONE) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: Vertex shader is required");
+    if (d->fragment_program == MIRHI_PROGRAM_NONE) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: Fragment shader is required");
+    if (d->color_attachment_count == 0) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: At least one color attachment format is required");
+    const bool has_depth = d->depth_attachment_format != MIRHI_FORMAT_UNDEFINED;
+    if ((d->depth_test_enable || d->depth_write_enable) && !has_depth)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: Depth test or write is enabled but no depth attachment format is specified");
+    if (d->blend_attachment_count != 0 && d->blend_attachment_count != d->color_attachment_count)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: Blend attachment count (%u) must match color attachment count (%u)", d->blend_attachment_count, d->color_attachment_count);
+    // --- program selection replaces SPIR-V module creation (shader.rs:244-330) ---
+    if (d->vertex_program < 0 || d->vertex_program > MIRHI_PROGRAM_MODEL_FULL || d->fragment_program < 0 || d->fragment_program > MIRHI_PROGRAM_MODEL_FULL)
+        return fail(MIRHI_ERR_SHADER, "Shader error: unknown program id (vertex %d, fragment %d)", d->vertex_program, d->fragment_program);
+    const bool vs_model = d->vertex_program != MIRHI_PROGRAM_TRIANGLE, fs_model = d->fragment_program != MIRHI_PROGRAM_TRIANGLE;
+    if (vs_model != fs_model)
+        return fail(MIRHI_ERR_SHADER, "Shader error: vertex program %d does not produce the inputs of fragment program %d", d->vertex_program, d->fragment_program);
+    // --- what this rasterizer does not implement fails loudly instead of rendering something else ---
+    if (d->color_attachment_count != 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: %u color attachments (exactly 1 supported)", d->color_attachment_count);
+    const int32_t cf = d->color_attachment_formats[0];
+    if (cf != MIRHI_FORMAT_B8G8R8A8_SRGB && cf != MIRHI_FORMAT_R32G32B32A32_SFLOAT)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported color attachment format %d", cf);
+    if (has_depth && d->depth_attachment_format != MIRHI_FORMAT_D32_SFLOAT)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported depth attachment format %d (D32_SFLOAT only)", d->depth_attachment_format);
+    if (d->topology != MIRHI_TOPOLOGY_TRIANGLE_LIST) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported topology %d (TriangleList only)", d->topology);
+    if (d->polygon_mode != MIRHI_POLYGON_FILL) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported polygon mode %d (Fill only)", d->polygon_mode);
+    if (d->cull_mode < 0 || d->cull_mode > 3 || d->front_face < 0 || d->front_face > 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid cull mode / front face");
+    if (d->depth_compare_op < 0 || d->depth_compare_op > 7) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid depth compare op %d", d->depth_compare_op);
+    if (d->rasterization_samples != 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported sample count %u", d->rasterization_samples);
+    if (d->blend_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: blending (opaque overwrite only)");
+    if (d->depth_clamp_enable || d->depth_bias_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth clamp / depth bias");
+    if (d->depth_test_enable && !d->depth_write_enable && d->depth_compare_op != MIRHI_COMPARE_ALWAYS && d->depth_compare_op != MIRHI_COMPARE_NEVER)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth test without depth write");
+    if (d->depth_test_enable && (d->depth_compare_op == MIRHI_COMPARE_EQUAL || d->depth_compare_op == MIRHI_COMPARE_NOT_EQUAL))
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported depth compare op %d (Equal / NotEqual)", d->depth_compare_op);
+    const uint32_t want_stride = vs_model ? 48u : 24u;      // vertex.rs:35-41 / :130-136
+    if (d->vertex_stride < want_stride || (d->vertex_stride & 3u))
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: vertex stride %u too small for program %d (needs >= %u, multiple of 4)", d->vertex_stride, d->vertex_program, want_stride);
+    const uint32_t want_attrs = vs_model ? 4u : 2u;
+    static const uint32_t model_offsets[4] = {0, 12, 24, 32}, tri_offsets[2] = {0, 12};
+    if (d->attribute_count != want_attrs) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: program %d expects %u vertex attributes, got %u", d->vertex_program, want_attrs, d->attribute_count);
+    for (uint32_t i = 0; i < want_attrs; i++)
+        if (d->attribute_offsets[i] != (vs_model ? model_offsets[i] : tri_offsets[i]))
+            return fail(MIRHI_ERR_PIPELINE, "Pipeline error: attribute %u offset %u does not match the reference vertex layout", i, d->attribute_offsets[i]);
+    mirhi_pipeline* p = new (std::nothrow) mirhi_pipeline{dev, *d};
+    if (!p) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    dev->children++;
+    *out = p;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_pipeline_destroy(mirhi_pipeline* p) {
+    NULL_CHECK(p, "pipeline");
+    p->dev->children--;
+    delete p;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// command recording (command.rs)
+// ------------------------------------------------------------------------------------------------
+extern "C" void mirhi_rendering_info_default(mirhi_rendering_info* i) {
+    if (!i) return;
+    memset(i, 0, sizeof *i);
+    i->color_load_op = MIRHI_LOAD_OP_CLEAR; i->color_store_op = MIRHI_STORE_OP_STORE;       // rendering.rs:102-115
+    i->clear_color[3] = 1.0f;
+    i->depth_load_op = MIRHI_LOAD_OP_CLEAR; i->depth_store_op = MIRHI_STORE_OP_DONT_CARE;   // rendering.rs:356-370
+    i->clear_depth = 1.0f;
+}
+
+static void free_workspace(mirhi_cmd* c) {
+    Workspace& w = c->ws;
+    if (w.draws) (void)hipFree(w.draws);
+    if (w.bin_recs) (void)hipFree(w.bin_recs);
+    if (w.counters) (void)hipFree(w.counters);
+    if (w.big_recs) (void)hipFree(w.big_recs);
+    if (w.status_host) (void)hipHostFree(w.status_host);
+    w = Workspace();
+}
+
+extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    mirhi_cmd* c = new (std::nothrow) mirhi_cmd();
+    if (!c) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    c->dev = dev;
+    dev->children++;
+    *out = c;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
+    NULL_CHECK(cmd, "command buffer");
+    (void)hipSetDevice(cmd->dev->ordinal);
+    (void)hipStreamSynchronize(cmd->dev->stream);
+    free_workspace(cmd);
+    cmd->dev->children--;
+    delete cmd;
+    return MIRHI_OK;
+}
+static void reset_recording(mirhi_cmd* c) {
+    c->passes.clear(); c->plan.clear(); c->plan_tris = 0;
+    c->in_rendering = false;
+    c->pipeline = nullptr; c->vb = nullptr; c->ib = nullptr;
+    for (auto& u : c->uniforms) u = {nullptr, 0, 0};
+    c->textures[0] = c->textures[1] = nullptr;
+    c->has_viewport = c->has_scissor = false;
+}
+static mirhi_result begin_common(mirhi_cmd* cmd, bool one_time) {
+    NULL_CHECK(cmd, "command buffer");
+    if (cmd->state == CMD_RECORDING) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer is already recording");
+    reset_recording(cmd);          // implicit reset, as with RESET_COMMAND_BUFFER pools (command.rs:89-106)
+    cmd->state = CMD_RECORDING;
+    cmd->one_time = one_time;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_begin(mirhi_cmd* cmd) { return begin_common(cmd, true); }
+extern "C" mirhi_result mirhi_cmd_begin_reusable(mirhi_cmd* cmd) { return begin_common(cmd, false); }
+extern "C" mirhi_result mirhi_cmd_reset(mirhi_cmd* cmd) {
+    NULL_CHECK(cmd, "command buffer");
+    reset_recording(cmd);
+    cmd->state = CMD_INITIAL;
+    return MIRHI_OK;
+}
+#define REQUIRE_RECORDING(cmd)                                                                         \
+    do {                                                                                               \
+        NULL_CHECK(cmd, "command buffer");                                                             \
+        if ((cmd)->state != CMD_RECORDING) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer is not in the recording state"); \
+    } while (0)
+
+extern "C" mirhi_result mirhi_cmd_begin_rendering(mirhi_cmd* cmd, const mirhi_rendering_info* info) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(info, "rendering_info");
+    if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: begin_rendering inside an active rendering scope");
+    NULL_CHECK(info->color_image, "color_image");
+    const mirhi_image* ci = info->color_image;
+    if (ci->format != MIRHI_FORMAT_B8G8R8A8_SRGB && ci->format != MIRHI_FORMAT_R32G32B32A32_SFLOAT)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: color attachment has non-colour format %d", (int)ci->format);
+    if (info->depth_image) {
+        if (info->depth_image->format != MIRHI_FORMAT_D32_SFLOAT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: depth attachment is not D32_SFLOAT");
+        if (info->depth_image->width != ci->width || info->depth_image->height != ci->height)
+            return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: depth attachment extent does not match the colour attachment");
+    }
+    if (info->prim_id_image) {
+        if (info->prim_id_image->format != MIRHI_FORMAT_R32_UINT || info->prim_id_image->width != ci->width || info->prim_id_image->height != ci->height)
+            return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: prim_id_image must be R32_UINT with the colour attachment's extent");
+    }
+    RecordedPass p;
+    p.info = *info;
+    if (info->render_area[2] <= 0 || info->render_area[3] <= 0) { p.area[0] = 0; p.area[1] = 0; p.area[2] = (int32_t)ci->width; p.area[3] = (int32_t)ci->height; }
+    else memcpy(p.area, info->render_area, sizeof p.area);
+    if (p.area[0] != 0 || p.area[1] != 0 || p.area[2] != (int32_t)ci->width || p.area[3] != (int32_t)ci->height)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unsupported: render area must cover the whole colour attachment");
+    cmd->passes.push_back(std::move(p));
+    cmd->in_rendering = true;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_end_rendering(mirhi_cmd* cmd) {
+    REQUIRE_RECORDING(cmd);
+    if (!cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end_rendering without begin_rendering");
+    cmd->in_rendering = false;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_bind_pipeline(mirhi_cmd* cmd, mirhi_pipeline* pipeline) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(pipeline, "pipeline");
+    cmd->pipeline = pipeline;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_bind_vertex_buffers(mirhi_cmd* cmd, uint32_t first_binding, uint32_t count, mirhi_buffer* const* buffers, const uint64_t* offsets) {
+    REQUIRE_RECORDING(cmd);
+    if (count == 0) return MIRHI_OK;
+    NULL_CHECK(buffers, "buffers"); NULL_CHECK(offsets, "offsets");
+    if (first_binding != 0 || count != 1) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: only vertex binding 0 exists (vertex.rs:35-41)");
+    NULL_CHECK(buffers[0], "buffers[0]");
+    if (offsets[0] >= buffers[0]->size || (offsets[0] & 3)) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: vertex buffer offset %llu out of range or unaligned", (unsigned long long)offsets[0]);
+    cmd->vb = buffers[0]; cmd->vb_offset = offsets[0];
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_bind_index_buffer(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, mirhi_index_type type) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(buffer, "buffer");
+    if (type != MIRHI_INDEX_UINT16 && type != MIRHI_INDEX_UINT32) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown index type %d", (int)type);
+    const uint64_t isz = type == MIRHI_INDEX_UINT16 ? 2 : 4;
+    if (offset >= buffer->size || (offset % isz)) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: index buffer offset %llu out of range or unaligned", (unsigned long long)offset);
+    cmd->ib = buffer; cmd->ib_offset = offset; cmd->ib_type = type;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_bind_uniform(mirhi_cmd* cmd, mirhi_uniform_slot slot, mirhi_buffer* buffer, uint64_t offset, uint64_t range) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(buffer, "buffer");
+    if ((int)slot < 0 || (int)slot >= MIRHI_SLOT_COUNT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown uniform slot %d", (int)slot);
+    if (range == 0 || range == UINT64_MAX) range = buffer->size > offset ? buffer->size - offset : 0;   // VK_WHOLE_SIZE
+    if (offset + range > buffer->size || range == 0 || (offset & 15))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: uniform range offset %llu + range %llu exceeds buffer %llu or offset not 16-byte aligned",
+                    (unsigned long long)offset, (unsigned long long)range, (unsigned long long)buffer->size);
+    cmd->uniforms[slot] = {buffer, offset, range};
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_bind_texture(mirhi_cmd* cmd, mirhi_texture_slot slot, mirhi_image* image) {
+    REQUIRE_RECORDING(cmd);
+    if ((int)slot < 0 || (int)slot >= MIRHI_TEXTURE_COUNT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown texture slot %d", (int)slot);
+    if (image && image->format != MIRHI_FORMAT_R8G8B8A8_UNORM) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: sampled images must be R8G8B8A8_UNORM");
+    cmd->textures[slot] = image;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_set_viewport(mirhi_cmd* cmd, const mirhi_viewport* vp) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(vp, "viewport");
+    if (!(vp->width > 0.0f) || !(vp->height != 0.0f) || !(vp->min_depth >= 0.0f && vp->min_depth <= 1.0f) || !(vp->max_depth >= 0.0f && vp->max_depth <= 1.0f))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: viewport width must be > 0, height != 0, depth range within [0,1]");
+    if (std::fabs(vp->x) + std::fabs(vp->width) > 8192.0f || std::fabs(vp->y) + std::fabs(vp->height) > 8192.0f)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: viewport exceeds the +-8192 px range supported by the guard band");
+    cmd->viewport = *vp; cmd->has_viewport = true;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_set_scissor(mirhi_cmd* cmd, const mirhi_rect2d* sc) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(sc, "scissor");
+    if (sc->x < 0 || sc->y < 0) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: scissor offset must be non-negative");
+    cmd->scissor = *sc; cmd->has_scissor = true;
+    return MIRHI_OK;
+}
+
+static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, uint32_t instance_count, uint32_t first, int32_t vertex_offset) {
+    REQUIRE_RECORDING(cmd);
+    if (!cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: draw outside a rendering scope");
+    if (!cmd->pipeline) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: no pipeline bound");
+    if (!cmd->vb) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: no vertex buffer bound to binding 0");
+    if (indexed && !cmd->ib) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: no index buffer bound");
+    if (!cmd->has_viewport || !cmd->has_scissor) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: viewport and scissor are dynamic state and must be set before drawing (pipeline.rs:697)");
+    if (instance_count > 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: instance_count %u (1 supported)", instance_count);
+    RecordedPass& pass = cmd->passes.back();
+    const mirhi_pipeline_desc& pd = cmd->pipeline->desc;
+    const mirhi_image* ci = pass.info.color_image;
+    if (pd.color_attachment_formats[0] != (int32_t)ci->format)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: pipeline colour format %d does not match the attachment format %d", pd.color_attachment_formats[0], (int)ci->format);
+    // depth state must be uniform within a rendering scope (DESIGN.md "Depth key")
+    const uint32_t dtest = pd.depth_test_enable && pd.depth_compare_op != MIRHI_COMPARE_ALWAYS ? 1u : 0u;
+    const uint32_t dcmp = dtest ? (uint32_t)pd.depth_compare_op : (uint32_t)MIRHI_COMPARE_ALWAYS;
+    const bool never = pd.depth_test_enable && pd.depth_compare_op == MIRHI_COMPARE_NEVER;
+    if (!never) {
+        if (!pass.key_set) { pass.key_set = true; pass.depth_test = dtest; pass.depth_compare = dcmp; }
+        else if (pass.depth_test != dtest || pass.depth_compare != dcmp)
+            return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: pipelines with different depth test state inside one rendering scope");
+    }
+    const uint32_t tri_count = count / 3u;
+    if (instance_count == 0 || tri_count == 0 || never) return MIRHI_OK;
+
+    DrawDesc d;
+    memset(&d, 0, sizeof d);
+    d.stride = pd.vertex_stride;
+    d.vb = cmd->vb->ptr + cmd->vb_offset;
+    const uint64_t vb_bytes = cmd->vb->size - cmd->vb_offset;
+    const uint32_t vsize = pd.vertex_program == MIRHI_PROGRAM_TRIANGLE ? 24u : 48u;
+    if (!indexed) {
+        const uint64_t last = (uint64_t)first + 3ull * tri_count;   // one past the last vertex read
+        if ((last - 1) * d.stride + vsize > vb_bytes)
+            return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: draw reads vertices [%u, %llu) beyond the bound vertex buffer (%llu bytes)", first, (unsigned long long)last, (unsigned long long)vb_bytes);
+        d.index_type = 0; d.first = first; d.vertex_offset = 0; d.ib = nullptr;
+    } else {
+        const uint64_t isz = cmd->ib_type == MIRHI_INDEX_UINT16 ? 2 : 4;
+        const uint64_t ib_bytes = cmd->ib->size - cmd->ib_offset;
+        if (((uint64_t)first + 3ull * tri_count) * isz > ib_bytes)
+            return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: draw_indexed reads indices [%u, %llu) beyond the bound index buffer", first, (unsigned long long)first + 3ull * tri_count);
+        d.index_type = (uint32_t)isz; d.first = first; d.vertex_offset = vertex_offset; d.ib = cmd->ib->ptr + cmd->ib_offset;
+    }
+    d.tri_count = tri_count;
+    d.prim_base = pass.total_tris;
+    if ((uint64_t)pass.total_tris + tri_count > (uint64_t)MAX_PRIM_ID) return fail(MIRHI_ERR_DEVICE, "Vulkan error: too many primitives in one rendering scope");
+    d.program = (uint32_t)pd.fragment_program;
+    d.cull_mode = (uint32_t)pd.cull_mode; d.front_face = (uint32_t)pd.front_face;
+    // uniforms required by the program (model.hlsl:5-19, model_full.hlsl:27-50)
+    auto uptr = [&](int slot, uint64_t need, const uint8_t** out, const char* name) -> mirhi_result {
+        auto& u = cmd->uniforms[slot];
+        if (!u.buf) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: program %d needs %s bound", pd.fragment_program, name);
+        if (u.range < need) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: %s range %llu smaller than %llu bytes", name, (unsigned long long)u.range, (unsigned long long)need);
+        *out = u.buf->ptr + u.offset;
+        return MIRHI_OK;
+    };
+    if (d.program != MIRHI_PROGRAM_TRIANGLE) {
+        const uint8_t* p = nullptr;
+        mirhi_result r;
+        if ((r = uptr(MIRHI_SLOT_CAMERA, 208, &p, "CameraData (b0)")) != MIRHI_OK) return r;
+        d.camera = (const float*)p;
+        if ((r = uptr(MIRHI_SLOT_OBJECT, 128, &p, "ObjectData (b1)")) != MIRHI_OK) return r;
+        d.object = (const float*)p;
+        if (d.program == MIRHI_PROGRAM_MODEL_FULL) {
+            if ((r = uptr(MIRHI_SLOT_LIGHTS, 48, &d.lights, "LightUBO (b2)")) != MIRHI_OK) return r;
+            if ((r = uptr(MIRHI_SLOT_MATERIAL, 32, &d.material, "MaterialData (b3)")) != MIRHI_OK) return r;
+            if (cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf) d.point_lights = cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].offset;
+            if (cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf) d.spot_lights = cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].offset;
+            for (int t = 0; t < 2; t++)
+                if (cmd->textures[t]) { d.tex[t] = cmd->textures[t]->ptr; d.tex_w[t] = cmd->textures[t]->width; d.tex_h[t] = cmd->textures[t]->height; }
+        }
+    }
+    // viewport (Vulkan: xf = (w/2) xd + (x + w/2)), guard-band factors, scissor
+    const mirhi_viewport& vp = cmd->viewport;
+    d.hw = 0.5f * vp.width; d.hh = 0.5f * vp.height;
+    d.cx = vp.x + d.hw; d.cy = vp.y + d.hh;
+    d.dscale = vp.max_depth - vp.min_depth; d.dmin = vp.min_depth;
+    d.gx = (GUARD_PX - std::fabs(d.cx)) / d.hw;
+    d.gy = (GUARD_PX - std::fabs(d.cy)) / d.hh;
+    int64_t sx0 = cmd->scissor.x, sy0 = cmd->scissor.y;
+    int64_t sx1 = sx0 + (int64_t)cmd->scissor.width - 1, sy1 = sy0 + (int64_t)cmd->scissor.height - 1;
+    if (sx1 > (int64_t)ci->width - 1) sx1 = (int64_t)ci->width - 1;
+    if (sy1 > (int64_t)ci->height - 1) sy1 = (int64_t)ci->height - 1;
+    d.sx0 = (int32_t)sx0; d.sy0 = (int32_t)sy0; d.sx1 = (int32_t)sx1; d.sy1 = (int32_t)sy1;
+    d.scissor_partial = (sx0 > 0 || sy0 > 0 || sx1 < (int64_t)ci->width - 1 || sy1 < (int64_t)ci->height - 1) ? 1u : 0u;
+    if (sx0 > sx1 || sy0 > sy1) return MIRHI_OK;    // empty scissor: nothing can be covered
+    pass.draws.push_back(d);
+    pass.total_tris += tri_count;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_draw(mirhi_cmd* cmd, uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance) {
+    (void)first_instance;
+    return record_draw(cmd, false, vertex_count, instance_count, first_vertex, 0);
+}
+extern "C" mirhi_result mirhi_cmd_draw_indexed(mirhi_cmd* cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance) {
+    (void)first_instance;
+    return record_draw(cmd, true, index_count, instance_count, first_index, vertex_offset);
+}
+
+// ---- end(): size the workspace and build the launch plan ------------------------------------------
+template <typename T>
+static mirhi_result grow(T** ptr, size_t* have, size_t want_bytes) {
+    if (*have >= want_bytes && *ptr) return MIRHI_OK;
+    if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want_bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc(%zu) for rasterizer workspace: %s", want_bytes, hipGetErrorString(e)); }
+    *ptr = (T*)p; *have = want_bytes;
+    return MIRHI_OK;
+}
+
+static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
+    const uint32_t cbits = [&] { float f = pass.info.clear_depth; f = f > 0.0f ? (f < 1.0f ? f : 1.0f) : 0.0f; uint32_t u; memcpy(&u, &f, 4); return u; }();
+    P.clear_depth_bits = cbits;
+    const uint32_t op = pass.key_set ? pass.depth_compare : (uint32_t)MIRHI_COMPARE_ALWAYS;
+    const bool test = pass.key_set && pass.depth_test;
+    if (!test || op == MIRHI_COMPARE_ALWAYS) { P.zflip = 0; P.zmask = 0; P.idflip = 1; P.strict = 0; P.init_zk = 0; P.init_idk = NO_PRIM; return; }
+    const bool greater = (op == MIRHI_COMPARE_GREATER || op == MIRHI_COMPARE_GREATER_OR_EQUAL);
+    P.strict = (op == MIRHI_COMPARE_LESS || op == MIRHI_COMPARE_GREATER) ? 1u : 0u;
+    P.zflip = greater ? 0xFFFFFFFFu : 0u;
+    P.zmask = 0xFFFFFFFFu;
+    P.idflip = P.strict ? 0u : 1u;            // strict: earlier primitive keeps ties; or-equal: later primitive wins
+    const uint32_t t = cbits ^ P.zflip;
+    if (!P.strict) { P.init_zk = t; P.init_idk = NO_PRIM; }
+    else if (t == 0u) { P.init_zk = 0u; P.init_idk = 0u; }   // nothing can pass
+    else { P.init_zk = t - 1u; P.init_idk = NO_PRIM; }
+}
+
+extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
+    REQUIRE_RECORDING(cmd);
+    if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
+    mirhi_device* dev = cmd->dev;
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    // the workspace may still be in use by an earlier submission of this command buffer
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    size_t total_draws = 0, max_tiles = 0, max_bin_bytes = 0, max_big = 0;
+    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, big_cap; };
+    std::vector<Geo> geo;
+    for (auto& pass : cmd->passes) {
+        const mirhi_image* ci = pass.info.color_image;
+        Geo g;
+        g.tiles_x = (ci->width + TILE - 1) / TILE; g.tiles_y = (ci->height + TILE - 1) / TILE;
+        band_tile_rows(dev, g.tiles_y, &g.r0, &g.r1);
+        const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
+        size_t cap = tiles ? (8ull * pass.total_tris) / tiles + 64 : 64;
+        cap = (cap + 63) & ~(size_t)63;
+        if (cap > 4096) cap = 4096;
+        g.bin_cap = (uint32_t)cap;
+        g.big_cap = pass.total_tris + pass.total_tris / 4 + 1024;
+        geo.push_back(g);
+        total_draws += pass.draws.size();
+        if (tiles > max_tiles) max_tiles = tiles;
+        if (tiles * cap * sizeof(TileRec) > max_bin_bytes) max_bin_bytes = tiles * cap * sizeof(TileRec);
+        if (g.big_cap > max_big) max_big = g.big_cap;
+    }
+    Workspace& w = cmd->ws;
+    mirhi_result r;
+    size_t draws_bytes = w.draws_cap * sizeof(DrawDesc);
+    if ((r = grow(&w.draws, &draws_bytes, (total_draws ? total_draws : 1) * sizeof(DrawDesc))) != MIRHI_OK) return r;
+    w.draws_cap = draws_bytes / sizeof(DrawDesc);
+    if ((r = grow(&w.bin_recs, &w.bin_recs_bytes, max_bin_bytes ? max_bin_bytes : sizeof(TileRec))) != MIRHI_OK) return r;
+    if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
+    size_t counter_bytes = w.counters_words * 4;
+    const size_t want_words = max_tiles + 8;
+    const bool fresh = !(w.counters && counter_bytes >= want_words * 4);
+    if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
+    w.counters_words = counter_bytes / 4;
+    (void)fresh;
+    HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, dev->stream));
+    if (!w.status_host) HIP_TRY(hipHostMalloc((void**)&w.status_host, 64, hipHostMallocDefault));
+    w.status_host[0] = 0; w.status_host[1] = 0;
+
+    // upload draw descriptors, build per-pass parameters
+    std::vector<DrawDesc> all;
+    all.reserve(total_draws);
+    cmd->plan.clear(); cmd->plan_tris = 0;
+    for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
+        RecordedPass& pass = cmd->passes[pi];
+        const Geo& g = geo[pi];
+        const mirhi_image* ci = pass.info.color_image;
+        PassParams P;
+        memset(&P, 0, sizeof P);
+        P.width = ci->width; P.height = ci->height;
+        P.tiles_x = g.tiles_x; P.tiles_y = g.tiles_y; P.tile_row_begin = g.r0; P.tile_row_end = g.r1;
+        P.num_draws = (uint32_t)pass.draws.size(); P.total_tris = pass.total_tris;
+        P.draws = w.draws + all.size();
+        depth_key_setup(P, pass);
+        memcpy(P.clear_color, pass.info.clear_color, sizeof P.clear_color);
+        P.color_load = pass.info.color_load_op == MIRHI_LOAD_OP_LOAD ? 1u : 0u;
+        P.color_format = (uint32_t)ci->format;
+        P.color = ci->ptr;
+        if (pass.info.depth_image) {
+            P.depth = (float*)pass.info.depth_image->ptr;
+            P.depth_load = pass.info.depth_load_op == MIRHI_LOAD_OP_LOAD ? 1u : 0u;
+            P.depth_store = pass.info.depth_store_op == MIRHI_STORE_OP_STORE ? 1u : 0u;
+        }
+        P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
+        P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
+        P.big_recs = w.big_recs; P.big_count = w.counters + max_tiles; P.big_cap = g.big_cap;
+        P.status = w.counters + max_tiles + 1;
+        all.insert(all.end(), pass.draws.begin(), pass.draws.end());
+        cmd->plan.push_back(P);
+        cmd->plan_tris += pass.total_tris;
+    }
+    if (!all.empty()) {
+        HIP_TRY(hipMemcpyAsync(w.draws, all.data(), all.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, dev->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(dev->stream));
+    dev->stats.workspace_bytes = w.bytes();
+    cmd->state = CMD_EXECUTABLE;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// submit + fences
+// ------------------------------------------------------------------------------------------------
+static mirhi_result profile_begin(mirhi_device* dev, EventPair* ev) {
+    if (!dev->free_events.empty()) { *ev = dev->free_events.back(); dev->free_events.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&ev->a)); HIP_TRY(hipEventCreate(&ev->b)); }
+    HIP_TRY(hipEventRecord(ev->a, dev->stream));
+    return MIRHI_OK;
+}
+
+extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence) {
+    NULL_CHECK(dev, "device");
+    if (cmd_count) NULL_CHECK(cmds, "cmds");
+    for (uint32_t i = 0; i < cmd_count; i++) {
+        NULL_CHECK(cmds[i], "cmds[i]");
+        if (cmds[i]->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: command buffer belongs to another device");
+        if (cmds[i]->state != CMD_EXECUTABLE) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer %u is not in the executable state (call end())", i);
+    }
+    if (fence && fence->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: fence belongs to another device");
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    std::lock_guard<std::mutex> lock(dev->mu);
+    for (uint32_t i = 0; i < cmd_count; i++) {
+        mirhi_cmd* c = cmds[i];
+        for (const PassParams& P : c->plan) {
+            HIP_TRY(hipMemsetAsync(P.big_count, 0, 4, dev->stream));
+            EventPair ev{};
+            if (dev->profiling) { mirhi_result r = profile_begin(dev, &ev); if (r != MIRHI_OK) return r; }
+            HIP_TRY(launch_geometry(P, dev->stream));
+            if (dev->profiling) {
+                HIP_TRY(hipEventRecord(ev.b, dev->stream));
+                dev->pending[MIRHI_KERNEL_GEOMETRY].push_back(ev);
+                mirhi_result r = profile_begin(dev, &ev); if (r != MIRHI_OK) return r;
+            }
+            HIP_TRY(launch_raster(P, dev->stream));
+            if (dev->profiling) { HIP_TRY(hipEventRecord(ev.b, dev->stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev); }
+            dev->stats.frames_submitted++;
+            dev->stats.triangles_submitted += P.total_tris;
+        }
+        if (!c->plan.empty()) {
+            const PassParams& L = c->plan.back();
+            HIP_TRY(hipMemcpyAsync(c->ws.status_host, L.status, 4, hipMemcpyDeviceToHost, dev->stream));
+            HIP_TRY(hipMemcpyAsync(c->ws.status_host + 1, L.big_count, 4, hipMemcpyDeviceToHost, dev->stream));
+        }
+    }
+    if (fence) {
+        if (!fence->event) HIP_TRY(hipEventCreateWithFlags(&fence->event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(fence->event, dev->stream));
+        fence->pending = true; fence->signaled = false;
+        fence->cmds.assign(cmds, cmds + cmd_count);
+    }
+    return MIRHI_OK;
+}
+
+extern "C" mirhi_result mirhi_fence_create(mirhi_device* dev, uint32_t signaled, mirhi_fence** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    mirhi_fence* f = new (std::nothrow) mirhi_fence();
+    if (!f) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    f->dev = dev; f->signaled = signaled != 0;
+    dev->children++;
+    *out = f;
+    return MIRHI_OK;
+}
+static mirhi_result fence_complete(mirhi_fence* f) {
+    f->pending = false; f->signaled = true;
+    mirhi_result r = MIRHI_OK;
+    for (mirhi_cmd* c : f->cmds) {
+        if (c->ws.status_host) {
+            f->dev->stats.last_status = c->ws.status_host[0];
+            f->dev->stats.last_big_list = c->ws.status_host[1];
+            if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)
+                r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer large-triangle list overflowed (%u entries); frame is incomplete", c->ws.status_host[1]);
+        }
+    }
+    f->cmds.clear();
+    return r;
+}
+extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
+    NULL_CHECK(f, "fence");
+    if (f->signaled) return MIRHI_OK;
+    if (!f->pending) {
+        // unsignaled and nothing submitted: Vulkan would block until the timeout
+        if (timeout_ns == UINT64_MAX) return fail(MIRHI_ERR_DEVICE, "Vulkan error: waiting forever on a fence that was never submitted");
+        std::this_thread::sleep_for(std::chrono::nanoseconds(timeout_ns < 1000000000ull ? timeout_ns : 1000000000ull));
+        return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+    }
+    HIP_TRY(hipSetDevice(f->dev->ordinal));
+    if (timeout_ns == UINT64_MAX) {
+        HIP_TRY(hipEventSynchronize(f->event));
+        return fence_complete(f);
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::nanoseconds(timeout_ns);
+    for (;;) {
+        hipError_t e = hipEventQuery(f->event);
+        if (e == hipSuccess) return fence_complete(f);
+        if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() >= deadline) return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        std::this_thread::yield();
+    }
+}
+extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
+    NULL_CHECK(f, "fence");
+    if (f->pending) {   // resetting a fence that is still in flight is invalid in Vulkan; drain it first
+        HIP_TRY(hipSetDevice(f->dev->ordinal));
+        HIP_TRY(hipEventSynchronize(f->event));
+        (void)fence_complete(f);
+    }
+    f->signaled = false;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_fence_status(mirhi_fence* f) {
+    NULL_CHECK(f, "fence");
+    if (f->signaled) return MIRHI_OK;
+    if (!f->pending) return MIRHI_NOT_READY;
+    (void)hipSetDevice(f->dev->ordinal);
+    hipError_t e = hipEventQuery(f->event);
+    if (e == hipSuccess) { (void)fence_complete(f); return MIRHI_OK; }
+    (void)hipGetLastError();
+    return MIRHI_NOT_READY;
+}
+extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
+    NULL_CHECK(f, "fence");
+    (void)hipSetDevice(f->dev->ordinal);
+    if (f->pending) (void)hipEventSynchronize(f->event);
+    if (f->event) (void)hipEventDestroy(f->event);
+    f->dev->children--;
+    delete f;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+extern "C" mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable) {
+    NULL_CHECK(dev, "device");
+    std::lock_guard<std::mutex> lock(dev->mu);
+    dev->profiling = enable != 0;
+    return MIRHI_OK;
+}
+static mirhi_result drain_events(mirhi_device* dev) {
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    for (int k = 0; k < MIRHI_KERNEL_COUNT; k++) {
+        for (auto& p : dev->pending[k]) {
+            HIP_TRY(hipEventSynchronize(p.b));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+            dev->total_ms[k] += ms; dev->launches[k]++;
+            dev->free_events.push_back(p);
+        }
+        dev->pending[k].clear();
+    }
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches) {
+    NULL_CHECK(dev, "device");
+    if ((int)kernel < 0 || (int)kernel >= MIRHI_KERNEL_COUNT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown kernel id %d", (int)kernel);
+    std::lock_guard<std::mutex> lock(dev->mu);
+    mirhi_result r = drain_events(dev);
+    if (r != MIRHI_OK) return r;
+    if (total_ms) *total_ms = dev->total_ms[kernel];
+    if (launches) *launches = dev->launches[kernel];
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
+    NULL_CHECK(dev, "device");
+    std::lock_guard<std::mutex> lock(dev->mu);
+    mirhi_result r = drain_events(dev);
+    if (r != MIRHI_OK) return r;
+    for (int k = 0; k < MIRHI_KERNEL_COUNT; k++) { dev->total_ms[k] = 0; dev->launches[k] = 0; }
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    std::lock_guard<std::mutex> lock(dev->mu);
+    *out = dev->stats;
+    return MIRHI_OK;
+}

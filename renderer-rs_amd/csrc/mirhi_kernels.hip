@@ -1,0 +1,705 @@
+// mirhi_kernels.hip -- gfx950 (CDNA4) kernels of the compute rasterizer.
+//
+// Two kernels per rendering scope (DESIGN.md "Kernels"):
+//   geometry_kernel  one lane per input triangle: index + vertex fetch, vertex-shader position,
+//                    clip / divide / viewport / snap / cull / depth-plane setup, then tile binning.
+//                    Restates SURVEY 8a rows a1, a2, a4, a5 (crates/rhi/src/vertex.rs:20-61,88-170;
+//                    command.rs:583-628; shaders/hlsl/vertex/{triangle,model}.hlsl;
+//                    pipeline.rs:645-698,976-986; renderer.rs:504-518).
+//   raster_kernel    one 256-lane workgroup per 32x32 tile: stages the tile's triangle records
+//                    through LDS, resolves coverage (integer edge functions, top-left rule) and
+//                    depth (64-bit key, registers only -- depth never leaves the CU unless a depth
+//                    image is attached), then runs the fragment programs on the winning primitive
+//                    of each pixel and stores the colour once.  Rows a6-a9 (pipeline.rs:976-1025;
+//                    rendering.rs:102-115,356-370; depth_buffer.rs:48; shaders/hlsl/pixel/*.hlsl;
+//                    lights.hlsli; swapchain.rs:561-570).
+//
+// Everything that decides coverage, depth or the winning primitive is integer arithmetic or IEEE
+// binary32 {+,-,*,/} in the order fixed by DESIGN.md "Pipeline specification"; this file is
+// compiled with -ffp-contract=off so results are bit-identical to the CPU oracle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mirhi_device.h"
+#include "mirhi_launch.h"
+
+namespace mirhi {
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ float ldf(const uint8_t* p, uint32_t off) { return *reinterpret_cast<const float*>(p + off); }
+__device__ __forceinline__ uint32_t ldu(const uint8_t* p, uint32_t off) { return *reinterpret_cast<const uint32_t*>(p + off); }
+
+// HLSL mul(M, v), M column-major (vertex/model.hlsl:44,48); accumulation order = oracle's.
+__device__ __forceinline__ f4 mat4_mul(const float* m, f4 v) {
+    f4 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * v.w;
+    r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
+    return r;
+}
+__device__ __forceinline__ f3 mat3_mul(const float* m, f3 v) {
+    f3 r;
+    r.x = (m[0] * v.x + m[4] * v.y) + m[8] * v.z;
+    r.y = (m[1] * v.x + m[5] * v.y) + m[9] * v.z;
+    r.z = (m[2] * v.x + m[6] * v.y) + m[10] * v.z;
+    return r;
+}
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 mul3(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 normalize3(f3 a) { float l = length3(a); return {a.x / l, a.y / l, a.z / l}; }
+__device__ __forceinline__ float saturatef(float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// a1/a2/a4: index fetch, vertex fetch, vertex-shader position
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fetch_index(const DrawDesc& D, uint32_t k) {
+    if (D.index_type == 0) return D.first + k;
+    uint32_t idx;
+    if (D.index_type == 2) idx = reinterpret_cast<const uint16_t*>(D.ib)[D.first + k];
+    else idx = reinterpret_cast<const uint32_t*>(D.ib)[D.first + k];
+    return (uint32_t)((int32_t)idx + D.vertex_offset);
+}
+
+__device__ __forceinline__ f4 vs_position(const DrawDesc& D, uint32_t vidx, f3* world) {
+    const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+    f4 p = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};
+    if (D.program == 0) {                                   // vertex/triangle.hlsl:19
+        if (world) *world = {p.x, p.y, p.z};
+        return p;
+    }
+    f4 w = mat4_mul(D.object, p);                           // vertex/model.hlsl:44
+    if (world) *world = {w.x, w.y, w.z};
+    return mat4_mul(D.camera + 32, w);                      // :48 (viewProjection @128 B)
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared triangle -> tile record
+// ------------------------------------------------------------------------------------------------
+struct ScreenTri {
+    int32_t X[3], Y[3];          // 1/256 px, orientation normalised (interior has E > 0)
+    float z0, zx, zy;
+    int32_t minx, maxx, miny, maxy;   // inclusive pixel bbox
+    uint32_t idk, boxed;
+};
+
+__device__ __forceinline__ void make_tile_rec(TileRec& r, const ScreenTri& t, int32_t tx, int32_t ty) {
+    const int64_t Ptx = 256 * (int64_t)(tx * TILE) + 128, Pty = 256 * (int64_t)(ty * TILE) + 128;
+    int32_t A[3], B[3], Q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int a = i, b = (i + 1) % 3;
+        const int32_t dx = t.X[b] - t.X[a], dy = t.Y[b] - t.Y[a];
+        A[i] = -dy; B[i] = dx;
+        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);
+        const int64_t e0 = (int64_t)A[i] * (Ptx - t.X[a]) + (int64_t)B[i] * (Pty - t.Y[a]) + (topleft ? 0 : -1);
+        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r
+        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
+        Q[i] = (int32_t)q;
+    }
+    r.Q[0] = Q[0]; r.Q[1] = Q[1]; r.Q[2] = Q[2];
+    r.A0 = A[0]; r.A1 = A[1]; r.A2 = A[2]; r.B0 = B[0]; r.B1 = B[1]; r.B2 = B[2];
+    r.x0f = (float)t.X[0] * (1.0f / 256.0f);
+    r.y0f = (float)t.Y[0] * (1.0f / 256.0f);
+    r.z0 = t.z0; r.zx = t.zx; r.zy = t.zy;
+    r.idk = t.idk;
+    // tile-relative pixel box and conservative 8x8 block mask
+    const int32_t ox = tx * TILE, oy = ty * TILE;
+    int32_t bx0 = t.minx - ox, bx1 = t.maxx - ox, by0 = t.miny - oy, by1 = t.maxy - oy;
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) {
+            const int32_t lx = bx * BLOCK, hx = lx + BLOCK - 1, ly = by * BLOCK, hy = ly + BLOCK - 1;
+            bool hit = !(hx < bx0 || lx > bx1 || hy < by0 || ly > by1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int32_t cxp = A[i] >= 0 ? hx : lx, cyp = B[i] >= 0 ? hy : ly;
+                hit = hit && (Q[i] + __mul24(A[i], cxp) + __mul24(B[i], cyp) >= 0);
+            }
+            mask |= hit ? (1u << (by * 4 + bx)) : 0u;
+        }
+    }
+    r.mask = mask | (t.boxed ? 0x80000000u : 0u);
+    r.box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5: screen-space setup of one (possibly clipped) triangle and emission into bins / big list
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_triangle(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t prim) {
+    ScreenTri t;
+    float z[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (!(c[i].w > 0.0f)) return;
+        const float iw = 1.0f / c[i].w;
+        const float xs = (c[i].x * iw) * D.hw + D.cx;
+        const float ys = (c[i].y * iw) * D.hh + D.cy;
+        const float zs = (c[i].z * iw) * D.dscale + D.dmin;
+        if (!(fabsf(xs) <= 16383.0f) || !(fabsf(ys) <= 16383.0f)) return;
+        t.X[i] = (int32_t)rintf(xs * 256.0f);
+        t.Y[i] = (int32_t)rintf(ys * 256.0f);
+        z[i] = zs;
+    }
+    const int64_t S = (int64_t)(t.X[1] - t.X[0]) * (int64_t)(t.Y[2] - t.Y[0]) -
+                      (int64_t)(t.X[2] - t.X[0]) * (int64_t)(t.Y[1] - t.Y[0]);
+    if (S == 0) return;
+    const bool front = (D.front_face == 0) ? (S < 0) : (S > 0);     // Vulkan: a = -S/2, CCW front <=> a > 0
+    if (D.cull_mode == 3) return;
+    if (D.cull_mode == 2 && !front) return;
+    if (D.cull_mode == 1 && front) return;
+    if (S < 0) {
+        int32_t ti = t.X[1]; t.X[1] = t.X[2]; t.X[2] = ti;
+        ti = t.Y[1]; t.Y[1] = t.Y[2]; t.Y[2] = ti;
+        float tz = z[1]; z[1] = z[2]; z[2] = tz;
+    }
+    const float inv256 = 1.0f / 256.0f;
+    const float fx1 = (float)(t.X[1] - t.X[0]) * inv256, fy1 = (float)(t.Y[1] - t.Y[0]) * inv256;
+    const float fx2 = (float)(t.X[2] - t.X[0]) * inv256, fy2 = (float)(t.Y[2] - t.Y[0]) * inv256;
+    const float area = fx1 * fy2 - fx2 * fy1;
+    const float dz1 = z[1] - z[0], dz2 = z[2] - z[0];
+    t.zx = (dz1 * fy2 - dz2 * fy1) / area;
+    t.zy = (dz2 * fx1 - dz1 * fx2) / area;
+    t.z0 = z[0];
+    int32_t xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
+    int32_t ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
+    int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
+    int32_t py0 = (ymin + 127) >> 8, py1 = (ymax - 128) >> 8;
+    const bool cut = D.scissor_partial && (px0 < D.sx0 || px1 > D.sx1 || py0 < D.sy0 || py1 > D.sy1);
+    px0 = max(px0, D.sx0); px1 = min(px1, D.sx1); py0 = max(py0, D.sy0); py1 = min(py1, D.sy1);
+    if (px0 > px1 || py0 > py1) return;
+    t.minx = px0; t.maxx = px1; t.miny = py0; t.maxy = py1;
+    t.boxed = cut ? 1u : 0u;
+    t.idk = P.idflip ? (MAX_PRIM_ID - prim) : prim;
+
+    const int32_t tx0 = px0 >> TILE_LOG2, tx1 = px1 >> TILE_LOG2;
+    int32_t ty0 = py0 >> TILE_LOG2, ty1 = py1 >> TILE_LOG2;
+    ty0 = max(ty0, (int32_t)P.tile_row_begin); ty1 = min(ty1, (int32_t)P.tile_row_end - 1);
+    if (ty0 > ty1) return;
+    bool spill = (tx1 - tx0 >= MAX_BIN_SPAN) || (ty1 - ty0 >= MAX_BIN_SPAN);
+    if (!spill) {
+        for (int32_t ty = ty0; ty <= ty1; ty++) {
+            for (int32_t tx = tx0; tx <= tx1; tx++) {
+                const uint32_t tile = (uint32_t)(ty - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx;
+                const uint32_t slot = atomicAdd(&P.bin_count[tile], 1u);
+                if (slot < P.bin_cap) {
+                    TileRec r;
+                    make_tile_rec(r, t, tx, ty);
+                    uint4* dst = reinterpret_cast<uint4*>(&P.bin_recs[(size_t)tile * P.bin_cap + slot]);
+                    const uint4* src = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) dst[k] = src[k];
+                } else {
+                    spill = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
+                }
+            }
+        }
+    }
+    if (spill) {
+        const uint32_t slot = atomicAdd(P.big_count, 1u);
+        if (slot < P.big_cap) {
+            BigRec b;
+            b.X0 = t.X[0]; b.Y0 = t.Y[0]; b.X1 = t.X[1]; b.Y1 = t.Y[1]; b.X2 = t.X[2]; b.Y2 = t.Y[2];
+            b.z0 = t.z0; b.zx = t.zx; b.zy = t.zy; b.idk = t.idk;
+            b.bx = (uint32_t)px0 | ((uint32_t)px1 << 16);
+            b.by = (uint32_t)py0 | ((uint32_t)py1 << 16);
+            b.boxed = t.boxed; b.pad[0] = b.pad[1] = b.pad[2] = 0;
+            uint4* dst = reinterpret_cast<uint4*>(&P.big_recs[slot]);
+            const uint4* src = reinterpret_cast<const uint4*>(&b);
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[k] = src[k];
+        } else {
+            atomicOr(P.status, STATUS_BIG_OVERFLOW);
+        }
+    }
+}
+
+// clip planes: near z>=0, far w-z>=0, guard band x,y within +-g*w (oracle: clip_polygon)
+__device__ __forceinline__ float plane_dist(int plane, f4 c, float gx, float gy) {
+    switch (plane) {
+        case 1: return c.z;
+        case 2: return c.w - c.z;
+        case 4: return c.x + gx * c.w;
+        case 8: return gx * c.w - c.x;
+        case 16: return c.y + gy * c.w;
+        default: return gy * c.w - c.y;
+    }
+}
+__device__ __forceinline__ uint32_t outcode_clip(f4 c, float gx, float gy) {
+    uint32_t oc = 0;
+    if (c.z < 0.0f) oc |= 1;
+    if (c.w - c.z < 0.0f) oc |= 2;
+    if (c.x + gx * c.w < 0.0f) oc |= 4;
+    if (gx * c.w - c.x < 0.0f) oc |= 8;
+    if (c.y + gy * c.w < 0.0f) oc |= 16;
+    if (gy * c.w - c.y < 0.0f) oc |= 32;
+    return oc;
+}
+__device__ __forceinline__ uint32_t outcode_view(f4 c) {
+    uint32_t oc = 0;
+    if (c.x < -c.w) oc |= 1; if (c.x > c.w) oc |= 2;
+    if (c.y < -c.w) oc |= 4; if (c.y > c.w) oc |= 8;
+    if (c.z < 0.0f) oc |= 16; if (c.z > c.w) oc |= 32;
+    return oc;
+}
+
+__device__ __noinline__ void clip_and_emit(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t any,
+                                           uint32_t prim) {
+    f4 bufa[12], bufb[12];
+    f4* in = bufa; f4* tmp = bufb;
+    in[0] = c[0]; in[1] = c[1]; in[2] = c[2];
+    int n = 3;
+    for (int plane = 1; plane <= 32 && n >= 3; plane <<= 1) {
+        if (!(any & plane)) continue;
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const f4 a = in[i], b = in[(i + 1) % n];
+            const float da = plane_dist(plane, a, D.gx, D.gy), db = plane_dist(plane, b, D.gx, D.gy);
+            const bool ina = da >= 0.0f, inb = db >= 0.0f;
+            if (ina) tmp[m++] = a;
+            if (ina != inb) {
+                f4 p, q; float dp, dq;
+                if (ina) { p = a; q = b; dp = da; dq = db; } else { p = b; q = a; dp = db; dq = da; }
+                const float tt = dp / (dp - dq);
+                tmp[m++] = {p.x + tt * (q.x - p.x), p.y + tt * (q.y - p.y), p.z + tt * (q.z - p.z), p.w + tt * (q.w - p.w)};
+            }
+        }
+        n = m;
+        f4* s = in; in = tmp; tmp = s;
+    }
+    for (int i = 1; i + 1 < n; i++) {
+        const f4 t[3] = {in[0], in[i], in[i + 1]};
+        emit_triangle(P, D, t, prim);
+    }
+}
+
+__device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim) {
+    uint32_t lo = 0, hi = P.num_draws;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (P.draws[mid].prim_base <= prim) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
+    const uint32_t gid = blockIdx.x * GEOM_THREADS + threadIdx.x;
+    if (gid >= P.total_tris) return;
+    const DrawDesc& D = P.draws[find_draw(P, gid)];
+    const uint32_t tri = gid - D.prim_base;
+    f4 c[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) c[k] = vs_position(D, fetch_index(D, 3u * tri + k), nullptr);
+    const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
+    if (o0 & o1 & o2) return;
+    const uint32_t any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
+    if (any == 0) emit_triangle(P, D, c, gid);
+    else clip_and_emit(P, D, c, any, gid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: fragment programs (shading is tolerance-checked, |dRGB| < 1e-4, not bit-exact)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float attenuation(float distance, float radius) {          // lights.hlsli:63-73
+    const float att = 1.0f / (distance * distance + 1.0f);
+    float falloff = saturatef(1.0f - distance / radius);
+    falloff = falloff * falloff;
+    return att * falloff;
+}
+__device__ __forceinline__ float roughness_to_shininess(float roughness) {             // lights.hlsli:152-159
+    const float r = roughness < 0.0f ? 0.0f : (roughness > 1.0f ? 1.0f : roughness);
+    return 2048.0f + (2.0f - 2048.0f) * r;
+}
+__device__ __forceinline__ f3 blinn_phong(f3 L, f3 V, f3 N, f3 lightColor, f3 albedo, float shininess) {  // :95-117
+    float NdotL = dot3(N, L);
+    if (!(NdotL > 0.0f)) NdotL = 0.0f;
+    const f3 diffuse = mul3(scale3(lightColor, NdotL), albedo);
+    if (NdotL <= 0.0f) return diffuse;
+    const f3 H = normalize3(add3(L, V));
+    float NdotH = dot3(N, H);
+    if (!(NdotH > 0.0f)) NdotH = 0.0f;
+    const float sp = powf(NdotH, shininess);
+    return add3(diffuse, scale3(lightColor, sp));
+}
+
+__device__ __forceinline__ f4 texel(const uint8_t* tex, int32_t w, int32_t h, int32_t x, int32_t y) {
+    x %= w; if (x < 0) x += w;
+    y %= h; if (y < 0) y += h;
+    const uint32_t p = reinterpret_cast<const uint32_t*>(tex)[(uint32_t)y * (uint32_t)w + (uint32_t)x];
+    const float s = 1.0f / 255.0f;
+    return {(float)(p & 0xFF) * s, (float)((p >> 8) & 0xFF) * s, (float)((p >> 16) & 0xFF) * s, (float)(p >> 24) * s};
+}
+// bilinear, repeat, no mips (see oracle sample_bilinear)
+__device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, uint32_t h, float u, float v) {
+    if (!tex || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
+    const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    const int32_t x0 = (int32_t)x0f, y0 = (int32_t)y0f;
+    const f4 c00 = texel(tex, w, h, x0, y0), c10 = texel(tex, w, h, x0 + 1, y0);
+    const f4 c01 = texel(tex, w, h, x0, y0 + 1), c11 = texel(tex, w, h, x0 + 1, y0 + 1);
+    f4 r;
+#define MIRHI_LERP2(f) { const float top = c00.f + (c10.f - c00.f) * ax; const float bot = c01.f + (c11.f - c01.f) * ax; r.f = top + (bot - top) * ay; }
+    MIRHI_LERP2(x) MIRHI_LERP2(y) MIRHI_LERP2(z) MIRHI_LERP2(w)
+#undef MIRHI_LERP2
+    return r;
+}
+
+struct Varyings { f3 world, normal, tangent, bitangent; float u, v; };
+
+__device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
+    return {(b[0] * a0.x + b[1] * a1.x) + b[2] * a2.x, (b[0] * a0.y + b[1] * a1.y) + b[2] * a2.y,
+            (b[0] * a0.z + b[1] * a1.z) + b[2] * a2.z};
+}
+
+// perspective-correct barycentrics of the pixel centre from the original clip-space triangle
+__device__ __forceinline__ void barycentrics(const DrawDesc& D, const f4 c[3], float pxc, float pyc, float b[3]) {
+    float ax[3], ay[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ax[k] = (c[k].x * D.hw + c[k].w * D.cx) - pxc * c[k].w;
+        ay[k] = (c[k].y * D.hh + c[k].w * D.cy) - pyc * c[k].w;
+    }
+    const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
+    const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
+    const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
+    const float inv = 1.0f / ((l0 + l1) + l2);
+    b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
+}
+
+__device__ __forceinline__ f4 shade_triangle_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
+    f4 c[3]; f3 col[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t vidx = fetch_index(D, 3u * tri + k);
+        const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+        c[k] = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};                      // vertex/triangle.hlsl:19-20
+        col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
+    }
+    float b[3];
+    barycentrics(D, c, pxc, pyc, b);
+    const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
+    return {o.x, o.y, o.z, 1.0f};
+}
+
+__device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
+    f4 c[3]; Varyings vv[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t vidx = fetch_index(D, 3u * tri + k);
+        const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+        f3 world;
+        c[k] = vs_position(D, vidx, &world);
+        const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
+        const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
+        const float tw = ldf(v, 44);
+        const f3 N = normalize3(mat3_mul(D.object + 16, n));                 // vertex/model.hlsl:51
+        f3 T = normalize3(mat3_mul(D.object, t));                            // :52
+        T = normalize3(sub3(T, scale3(N, dot3(T, N))));                      // :55
+        const f3 B = scale3(cross3(N, T), tw);                               // :58
+        vv[k].world = world; vv[k].normal = N; vv[k].tangent = T; vv[k].bitangent = B;
+        vv[k].u = ldf(v, 24); vv[k].v = ldf(v, 28);
+    }
+    float b[3];
+    barycentrics(D, c, pxc, pyc, b);
+    const f3 worldPos = interp3(b, vv[0].world, vv[1].world, vv[2].world);
+    const f3 Nv = interp3(b, vv[0].normal, vv[1].normal, vv[2].normal);
+    const f3 camPos = {D.camera[48], D.camera[49], D.camera[50]};          // cameraPosition @192 B
+    const f3 V = normalize3(sub3(camPos, worldPos));
+
+    if (D.program == 1) {                                                    // pixel/model.hlsl:29-82
+        const f3 albedo = {0.7f, 0.7f, 0.7f};
+        const f3 one = {1.0f, 1.0f, 1.0f};
+        const f3 L = normalize3(one);
+        const f3 N = normalize3(Nv);
+        const f3 ambient = scale3(scale3(albedo, 0.03f), 1.0f);
+        const f3 lighting = blinn_phong(L, V, N, scale3(one, 1.0f), albedo, roughness_to_shininess(0.5f));
+        const f3 col = add3(ambient, lighting);
+        return {col.x, col.y, col.z, 1.0f};
+    }
+    // pixel/model_full.hlsl:85-150
+    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
+    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+    const f4 baseColor = {ldf(D.material, 0), ldf(D.material, 4), ldf(D.material, 8), ldf(D.material, 12)};
+    const float roughness = ldf(D.material, 20), ao = ldf(D.material, 24);
+    const f4 albedoSample = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+    const f3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
+    const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+    const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
+    const bool hasNormalMap = length3(ncm1) > 0.01f;                         // :94-95
+    f3 N = normalize3(Nv);
+    if (hasNormalMap) {                                                      // GetWorldNormal :63-83
+        const f3 ns = {nc.x * 2.0f - 1.0f, nc.y * 2.0f - 1.0f, nc.z * 2.0f - 1.0f};
+        const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
+        const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+        N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
+    }
+    const f3 ambient = scale3(scale3(albedo, 0.03f), ao);
+    f3 lighting = {0.0f, 0.0f, 0.0f};
+    const float shininess = roughness_to_shininess(roughness);
+    {   // CalculateDirectionalLight lights.hlsli:166-179 (HLSL DirectionalLight layout :17-23)
+        const f3 dir = {ldf(D.lights, 0), ldf(D.lights, 4), ldf(D.lights, 8)};
+        const float intensity = ldf(D.lights, 12);
+        const f3 color = {ldf(D.lights, 16), ldf(D.lights, 20), ldf(D.lights, 24)};
+        const f3 L = normalize3({-dir.x, -dir.y, -dir.z});
+        lighting = add3(lighting, blinn_phong(L, V, N, scale3(color, intensity), albedo, shininess));
+    }
+    const uint32_t numPoint = D.point_lights ? ldu(D.lights, 32) : 0u;
+    const uint32_t numSpot = D.spot_lights ? ldu(D.lights, 36) : 0u;
+    for (uint32_t i = 0; i < numPoint; i++) {                                // CalculatePointLight :182-199
+        const uint8_t* Lp = D.point_lights + 32u * i;
+        const f3 pos = {ldf(Lp, 0), ldf(Lp, 4), ldf(Lp, 8)};
+        const float radius = ldf(Lp, 12);
+        const f3 color = {ldf(Lp, 16), ldf(Lp, 20), ldf(Lp, 24)};
+        const float intensity = ldf(Lp, 28);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = {lv.x / dist, lv.y / dist, lv.z / dist};
+        const f3 lc = scale3(scale3(color, intensity), attenuation(dist, radius));
+        lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
+    }
+    for (uint32_t j = 0; j < numSpot; j++) {                                 // CalculateSpotLight :202-231
+        const uint8_t* Ls = D.spot_lights + 48u * j;
+        const f3 pos = {ldf(Ls, 0), ldf(Ls, 4), ldf(Ls, 8)};
+        const float innerCos = ldf(Ls, 12);
+        const f3 sdir = {ldf(Ls, 16), ldf(Ls, 20), ldf(Ls, 24)};
+        const float outerCos = ldf(Ls, 28);
+        const f3 color = {ldf(Ls, 32), ldf(Ls, 36), ldf(Ls, 40)};
+        const float intensity = ldf(Ls, 44);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = {lv.x / dist, lv.y / dist, lv.z / dist};
+        const float datt = attenuation(dist, 50.0f);
+        const f3 sd = normalize3(sdir);
+        const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);                // CalculateSpotAttenuation :77-81
+        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        const f3 lc = scale3(scale3(scale3(color, intensity), datt), satt);
+        lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
+    }
+    const f3 col = add3(ambient, lighting);
+    return {col.x, col.y, col.z, albedoSample.w * baseColor.w};
+}
+
+// a9: sRGB OETF + UNORM8, BGRA byte order (swapchain.rs:561-570)
+__device__ __forceinline__ uint32_t srgb8(float c) {
+    c = saturatef(c);
+    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    e = saturatef(e);
+    return (uint32_t)rintf(e * 255.0f);
+}
+__device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c) {
+    return srgb8(c.z) | (srgb8(c.y) << 8) | (srgb8(c.x) << 16) | ((uint32_t)rintf(saturatef(c.w) * 255.0f) << 24);
+}
+
+// ------------------------------------------------------------------------------------------------
+// raster kernel
+// ------------------------------------------------------------------------------------------------
+struct PixelState { uint32_t zk[4], idk[4]; };
+
+__device__ __forceinline__ void raster_chunk(const TileRec* __restrict__ lds, uint32_t n, uint32_t qmask,
+                                             int32_t ix0, int32_t iy0, float pxc0, float pyc0, const PassParams& P,
+                                             PixelState& st, uint32_t qbit0) {
+    for (uint32_t j = 0; j < n; j++) {
+        const uint32_t m = __builtin_amdgcn_readfirstlane(lds[j].mask);
+        if (!(m & qmask)) continue;
+        const uint4 w0 = reinterpret_cast<const uint4*>(&lds[j])[0];
+        const uint4 w1 = reinterpret_cast<const uint4*>(&lds[j])[1];
+        const uint4 w2 = reinterpret_cast<const uint4*>(&lds[j])[2];
+        const uint4 w3 = reinterpret_cast<const uint4*>(&lds[j])[3];
+        const int32_t Q0 = (int32_t)w0.x, Q1 = (int32_t)w0.y, Q2 = (int32_t)w0.z;
+        const int32_t A0 = (int32_t)w0.w, A1 = (int32_t)w1.x, A2 = (int32_t)w1.y;
+        const int32_t B0 = (int32_t)w1.z, B1 = (int32_t)w1.w, B2 = (int32_t)w2.x;
+        const float x0f = __uint_as_float(w2.y), y0f = __uint_as_float(w2.z), z0 = __uint_as_float(w2.w);
+        const float zx = __uint_as_float(w3.x), zy = __uint_as_float(w3.y);
+        const uint32_t idk = w3.z;
+        const int32_t s0 = Q0 + __mul24(A0, ix0) + __mul24(B0, iy0);
+        const int32_t s1 = Q1 + __mul24(A1, ix0) + __mul24(B1, iy0);
+        const int32_t s2 = Q2 + __mul24(A2, ix0) + __mul24(B2, iy0);
+        uint32_t box = 0;
+        const bool boxed = (m & 0x80000000u) != 0;
+        if (boxed) box = lds[j].box;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int bx = b & 1, by = b >> 1;
+            if (!(m & (qbit0 << (by * 4 + bx)))) continue;
+            const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK;
+            const int32_t S1 = s1 + (A1 * bx + B1 * by) * BLOCK;
+            const int32_t S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
+            bool inside = (S0 | S1 | S2) >= 0;
+            if (boxed) {
+                const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
+                inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
+                         iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
+            }
+            const float dx = (pxc0 + (float)(bx * BLOCK)) - x0f;
+            const float dy = (pyc0 + (float)(by * BLOCK)) - y0f;
+            float z = (z0 + dx * zx) + dy * zy;
+            z = z > 0.0f ? (z < 1.0f ? z : 1.0f) : 0.0f;
+            const uint32_t zk = (__float_as_uint(z) ^ P.zflip) & P.zmask;
+            const uint64_t key = ((uint64_t)zk << 32) | idk;
+            const uint64_t cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+            if (inside && key < cur) { st.zk[b] = zk; st.idk[b] = idk; }
+        }
+    }
+}
+
+__device__ __forceinline__ void init_key(const PassParams& P, uint32_t px, uint32_t py, bool valid, uint32_t& zk,
+                                         uint32_t& idk, uint32_t& zorig) {
+    zk = P.init_zk; idk = P.init_idk; zorig = P.clear_depth_bits;
+    if (P.depth_load && P.depth && valid) {
+        const uint32_t bits = __float_as_uint(P.depth[(size_t)py * P.width + px]);
+        zorig = bits;
+        if (P.zmask) {
+            const uint32_t t = bits ^ P.zflip;
+            if (!P.strict) { zk = t; idk = NO_PRIM; }
+            else if (t == 0u) { zk = 0u; idk = 0u; }
+            else { zk = t - 1u; idk = NO_PRIM; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RASTER_THREADS) void raster_kernel(const PassParams P) {
+    __shared__ TileRec lds[RASTER_THREADS];
+    __shared__ uint32_t lds_count;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, q = tid >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % P.tiles_x, ty = P.tile_row_begin + tile / P.tiles_x;
+    const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
+    const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
+    const float pxc0 = (float)px0 + 0.5f, pyc0 = (float)py0 + 0.5f;
+    // the four 8x8 blocks of quadrant q are bits (2*(q>>1)+by)*4 + 2*(q&1)+bx of the record's block mask
+    const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
+    const uint32_t qmask = qbit0 * 0x33u;
+
+    PixelState st;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+        uint32_t zo;
+        init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
+    }
+
+    // ---- per-tile bin -------------------------------------------------------------------------
+    if (tid == 0) {
+        const uint32_t c = P.bin_count[tile];
+        lds_count = c < P.bin_cap ? c : P.bin_cap;
+        P.bin_count[tile] = 0;                       // ready for the next scope that uses this workspace
+    }
+    __syncthreads();
+    const uint32_t count = lds_count;
+    const uint4* bin = reinterpret_cast<const uint4*>(P.bin_recs + (size_t)tile * P.bin_cap);
+    for (uint32_t base = 0; base < count; base += RASTER_THREADS) {
+        const uint32_t n = min((uint32_t)RASTER_THREADS, count - base);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (uint32_t e = tid; e < n * 5u; e += RASTER_THREADS) dst[e] = bin[(size_t)base * 5u + e];
+        __syncthreads();
+        raster_chunk(lds, n, qmask, ix0, iy0, pxc0, pyc0, P, st, qbit0);
+        __syncthreads();
+    }
+
+    // ---- big list: every tile tests every large / spilled triangle ------------------------------
+    const uint32_t nbig_raw = *P.big_count;
+    const uint32_t nbig = nbig_raw < P.big_cap ? nbig_raw : P.big_cap;
+    const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
+    for (uint32_t base = 0; base < nbig; base += RASTER_THREADS) {
+        if (tid == 0) lds_count = 0;
+        __syncthreads();
+        const uint32_t i = base + tid;
+        bool hit = false;
+        ScreenTri t;
+        if (i < nbig) {
+            const uint4* src = reinterpret_cast<const uint4*>(&P.big_recs[i]);
+            const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            t.minx = (int32_t)(w2.z & 0xFFFFu); t.maxx = (int32_t)(w2.z >> 16);
+            t.miny = (int32_t)(w2.w & 0xFFFFu); t.maxy = (int32_t)(w2.w >> 16);
+            hit = !(t.maxx < tpx0 || t.minx > tpx0 + TILE - 1 || t.maxy < tpy0 || t.miny > tpy0 + TILE - 1);
+            t.X[0] = (int32_t)w0.x; t.Y[0] = (int32_t)w0.y; t.X[1] = (int32_t)w0.z; t.Y[1] = (int32_t)w0.w;
+            t.X[2] = (int32_t)w1.x; t.Y[2] = (int32_t)w1.y;
+            t.z0 = __uint_as_float(w1.z); t.zx = __uint_as_float(w1.w); t.zy = __uint_as_float(w2.x);
+            t.idk = w2.y; t.boxed = w3.x;
+        }
+        TileRec r;
+        if (hit) {
+            make_tile_rec(r, t, (int32_t)tx, (int32_t)ty);
+            hit = (r.mask & 0xFFFFu) != 0;
+        }
+        // wave-level compaction: ballot + prefix popcount, one LDS atomic per wave
+        const uint64_t ball = __ballot(hit);
+        uint32_t wbase = 0;
+        if (lane == 0 && ball) wbase = atomicAdd(&lds_count, (uint32_t)__popcll(ball));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (hit) {
+            const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+            uint4* dst = reinterpret_cast<uint4*>(&lds[slot]);
+            const uint4* src = reinterpret_cast<const uint4*>(&r);
+#pragma unroll
+            for (int k = 0; k < 5; k++) dst[k] = src[k];
+        }
+        __syncthreads();
+        const uint32_t n = lds_count;
+        if (n) raster_chunk(lds, n, qmask, ix0, iy0, pxc0, pyc0, P, st, qbit0);
+        __syncthreads();
+    }
+
+    // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+        if (px >= P.width || py >= P.height) continue;
+        uint32_t izk, iidk, zorig;
+        init_key(P, px, py, true, izk, iidk, zorig);
+        const bool none = (st.zk[b] == izk) && (st.idk[b] == iidk);
+        const size_t pix = (size_t)py * P.width + px;
+        uint32_t prim = NO_PRIM;
+        f4 col = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
+        if (!none) {
+            prim = P.idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b];
+            const DrawDesc& D = P.draws[find_draw(P, prim)];
+            const uint32_t tri = prim - D.prim_base;
+            const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
+            col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program(D, tri, pxc, pyc);
+        }
+        if (!(none && P.color_load)) {
+            if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
+            else reinterpret_cast<uint32_t*>(P.color)[pix] = pack_bgra8_srgb(col);
+        }
+        if (P.prim_out) P.prim_out[pix] = prim;
+        if (P.depth && P.depth_store) {
+            const uint32_t zb = (none || !P.zmask) ? zorig : (st.zk[b] ^ P.zflip);
+            P.depth[pix] = __uint_as_float(zb);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (host side of this translation unit)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_geometry(const PassParams& P, hipStream_t stream) {
+    if (P.total_tris == 0) return hipSuccess;
+    const uint32_t blocks = (P.total_tris + GEOM_THREADS - 1) / GEOM_THREADS;
+    hipLaunchKernelGGL(geometry_kernel, dim3(blocks), dim3(GEOM_THREADS), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster(const PassParams& P, hipStream_t stream) {
+    const uint32_t rows = P.tile_row_end - P.tile_row_begin;
+    if (rows == 0 || P.tiles_x == 0) return hipSuccess;
+    hipLaunchKernelGGL(raster_kernel, dim3(P.tiles_x * rows), dim3(RASTER_THREADS), 0, stream, P);
+    return hipGetLastError();
+}
+
+}  // namespace mirhi

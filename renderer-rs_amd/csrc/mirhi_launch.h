@@ -1,0 +1,10 @@
+// mirhi_launch.h -- host-callable launchers of the kernels in mirhi_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mirhi_device.h"
+
+namespace mirhi {
+hipError_t launch_geometry(const PassParams& P, hipStream_t stream);
+hipError_t launch_raster(const PassParams& P, hipStream_t stream);
+}  // namespace mirhi

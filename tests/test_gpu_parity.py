@@ -1,0 +1,110 @@
+"""GPU parity tests: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): winning primitive id per pixel bit-exact, stored depth bit-exact,
+linear float colour |dRGB| < 1e-4, sRGB8 output within 1 LSB.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+
+
+def _render_both(mirhi, oracle, device, scene, fmt=None, want_depth=False):
+    fmt = mirhi.Format.R32G32B32A32_SFLOAT if fmt is None else fmt
+    res = mirhi.SceneResources(device, scene, fmt, want_prim=True, want_depth=want_depth)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=True)
+    return out, ref
+
+
+def _check(out, ref, name, depth=False):
+    diff = out["prim"] != ref["prim"]
+    assert not diff.any(), f"{name}: {int(diff.sum())} pixels differ in winning primitive id (first at {np.argwhere(diff)[0]})"
+    if out["color"].dtype == np.float32:
+        # compare where finite in the oracle; NaNs must agree
+        a, b = out["color"][..., :4], ref["rgba"]
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), f"{name}: NaN pattern differs"
+        err = np.abs(np.where(nan_b, 0, a) - np.where(nan_b, 0, b))
+        # tolerance is absolute on [0,1]; HDR values (float target is unclamped) get the same relative bound
+        scale = np.maximum(1.0, np.abs(np.where(nan_b, 0, b)))
+        worst = float((err / scale).max())
+        assert worst < RGB_TOL, f"{name}: max |dRGBA| = {worst}"
+    else:
+        d = np.abs(out["color"].astype(np.int32) - ref["bgra8"].astype(np.int32))
+        assert d.max() <= 1, f"{name}: sRGB8 differs by {d.max()} LSB"
+    if depth:
+        covered = ref["prim"] != 0xFFFFFFFF
+        assert np.array_equal(out["depth"].view(np.uint32)[covered], ref["depth"].view(np.uint32)[covered]), f"{name}: depth bits differ"
+
+
+@pytest.mark.parametrize("case", ["hello", "fan", "near_clip", "depth_tie", "cull_scissor", "multi_draw", "huge",
+                                  "textured", "random_small", "sphere_small"])
+def test_small_cases_float(mirhi, oracle, device, scenes, case):
+    scene = scenes.SMALL_CASES[case]()
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=any(d.depth_test for d in scene.draws))
+    _check(out, ref, scene.name, depth=any(d.depth_test for d in scene.draws))
+
+
+@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured"])
+def test_small_cases_srgb8(mirhi, oracle, device, scenes, case):
+    scene = scenes.SMALL_CASES[case]()
+    out, ref = _render_both(mirhi, oracle, device, scene, fmt=mirhi.Format.B8G8R8A8_SRGB)
+    _check(out, ref, scene.name)
+
+
+def test_hello_triangle_kat(mirhi, device, scenes):
+    """K2: 8192 covered pixels, rows 65..191, row 65 = x{127,128}, row 191 = x 64..191."""
+    scene = scenes.hello_triangle(256, 256)
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    cov = out["prim"] != 0xFFFFFFFF
+    assert int(cov.sum()) == 8192
+    rows = np.where(cov.any(axis=1))[0]
+    assert rows.min() == 65 and rows.max() == 191
+    assert list(np.where(cov[65])[0]) == [127, 128]
+    assert np.where(cov[191])[0].min() == 64 and np.where(cov[191])[0].max() == 191
+    assert np.allclose(out["color"][0, 0], [0.1, 0.1, 0.15, 1.0])
+
+
+@pytest.mark.parametrize("compare", ["Less", "LessOrEqual", "Greater", "GreaterOrEqual", "Always"])
+def test_depth_compare_ops(mirhi, oracle, device, scenes, compare):
+    op = getattr(mirhi.CompareOp, compare)
+    scene = scenes.depth_tie_case()
+    extra = scenes.random_triangles(60, scene.width, scene.height, seed=77, rmin=5, rmax=40).draws[0]
+    scene.draws.append(extra)
+    for d in scene.draws:
+        d.depth_compare = op
+    scene.clear_depth = 0.0 if "Greater" in compare else 1.0
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=True)
+    _check(out, ref, f"depth-{compare}", depth=(compare != "Always"))
+
+
+def test_config2_10k_triangles_1080p(mirhi, oracle, device, scenes):
+    scene = scenes.random_triangles()
+    out, ref = _render_both(mirhi, oracle, device, scene)
+    _check(out, ref, scene.name)
+
+
+def test_config3_sphere_70k(mirhi, oracle, device, scenes):
+    scene = scenes.displaced_sphere()
+    out, ref = _render_both(mirhi, oracle, device, scene)
+    _check(out, ref, scene.name)
+
+
+def test_determinism_and_resubmit(mirhi, device, scenes):
+    scene = scenes.random_triangles(2000, 640, 360, seed=5)
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render()
+    a = res.read()
+    for _ in range(3):
+        res.render()
+    b = res.read()
+    res.destroy()
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["color"], b["color"])
