@@ -61,8 +61,8 @@ static v3 cross3(v3 a, v3 b) {
     return r;
 }
 static float length3(v3 a) { return sqrtf(dot3(a, a)); }
-/* HLSL normalize = v * rsqrt(dot(v,v)); restated as v / sqrt(dot) */
-static v3 normalize3(v3 a) { float l = length3(a); v3 r = {a.x / l, a.y / l, a.z / l}; return r; }
+/* HLSL normalize = v * rsqrt(dot(v,v)); restated with a correctly rounded 1/sqrt */
+static v3 normalize3(v3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); v3 r = {a.x * inv, a.y * inv, a.z * inv}; return r; }
 static float saturatef(float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; }
 
 /* ------------------------------------------------------------------------------------------------
@@ -474,7 +474,7 @@ static void shade_pixel(const oracle_pass* pass, const oracle_draw* d, uint32_t 
         float intensity = rdf(L, 28);
         v3 lightVec = sub3(pos, worldPos);
         float dist = length3(lightVec);
-        v3 lightDir = {lightVec.x / dist, lightVec.y / dist, lightVec.z / dist};
+        v3 lightDir = scale3(lightVec, 1.0f / dist);      /* lightVec / distance */
         float att = oracle_attenuation(dist, radius);
         v3 lightColor = scale3(scale3(color, intensity), att);
         lighting = add3(lighting, blinn_phong(lightDir, V, N, lightColor, albedo, shininess));
@@ -489,7 +489,7 @@ static void shade_pixel(const oracle_pass* pass, const oracle_draw* d, uint32_t 
         float intensity = rdf(L, 44);
         v3 lightVec = sub3(pos, worldPos);
         float dist = length3(lightVec);
-        v3 lightDir = {lightVec.x / dist, lightVec.y / dist, lightVec.z / dist};
+        v3 lightDir = scale3(lightVec, 1.0f / dist);      /* lightVec / distance */
         float datt = oracle_attenuation(dist, 50.0f);
         float satt = spot_attenuation(lightDir, normalize3(sdir), innerCos, outerCos);
         v3 lightColor = scale3(scale3(scale3(color, intensity), datt), satt);
@@ -532,7 +532,7 @@ static void* band_run(void* arg) {
                 if ((t->A[1] * Px + t->B[1] * Py + t->C[1]) < 0) continue;
                 if ((t->A[2] * Px + t->B[2] * Py + t->C[2]) < 0) continue;
                 const float dx = ((float)x + 0.5f) - t->x0f;
-                float z = (t->z0 + dx * t->zx) + dy * t->zy;
+                float z = fmaf(dy, t->zy, fmaf(dx, t->zx, t->z0));   /* two fused multiply-adds, single rounding each */
                 z = z > 0.0f ? (z < 1.0f ? z : 1.0f) : 0.0f;
                 size_t idx = (size_t)y * W + (size_t)x;
                 int pass_test = d->depth_test ? depth_cmp(d->depth_compare, z, j->depth[idx]) : 1;

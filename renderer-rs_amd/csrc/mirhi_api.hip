@@ -129,7 +129,10 @@ struct Workspace {
     TileRec* bin_recs = nullptr; size_t bin_recs_bytes = 0;
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
-    uint32_t* status_host = nullptr;                             // pinned: [status, big_count]
+    uint32_t* status_host = nullptr;                             // pinned, device-mapped: [status bits, big-list length]
+    uint32_t* status_dev = nullptr;                              // device view of status_host
+    uint32_t* big_counts = nullptr;                              // two counters, used alternately (parity)
+    uint32_t parity = 0;
     size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes; }
 };
 
@@ -153,6 +156,7 @@ struct mirhi_cmd {
     // device-side plan, built at end()
     Workspace ws;
     std::vector<PassParams> plan;
+    std::vector<uint32_t> plan_programs;
     uint64_t plan_tris = 0;
 };
 
@@ -534,7 +538,7 @@ extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     return MIRHI_OK;
 }
 static void reset_recording(mirhi_cmd* c) {
-    c->passes.clear(); c->plan.clear(); c->plan_tris = 0;
+    c->passes.clear(); c->plan.clear(); c->plan_programs.clear(); c->plan_tris = 0;
     c->in_rendering = false;
     c->pipeline = nullptr; c->vb = nullptr; c->ib = nullptr;
     for (auto& u : c->uniforms) u = {nullptr, 0, 0};
@@ -820,13 +824,18 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     w.counters_words = counter_bytes / 4;
     (void)fresh;
     HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, dev->stream));
-    if (!w.status_host) HIP_TRY(hipHostMalloc((void**)&w.status_host, 64, hipHostMallocDefault));
+    if (!w.status_host) {
+        HIP_TRY(hipHostMalloc((void**)&w.status_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void**)&w.status_dev, w.status_host, 0));
+    }
     w.status_host[0] = 0; w.status_host[1] = 0;
+    w.big_counts = w.counters + max_tiles;
+    w.parity = 0;
 
     // upload draw descriptors, build per-pass parameters
     std::vector<DrawDesc> all;
     all.reserve(total_draws);
-    cmd->plan.clear(); cmd->plan_tris = 0;
+    cmd->plan.clear(); cmd->plan_programs.clear(); cmd->plan_tris = 0;
     for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
         RecordedPass& pass = cmd->passes[pi];
         const Geo& g = geo[pi];
@@ -849,10 +858,16 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         }
         P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
-        P.big_recs = w.big_recs; P.big_count = w.counters + max_tiles; P.big_cap = g.big_cap;
-        P.status = w.counters + max_tiles + 1;
+        P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
+        P.status = w.status_dev;
+        uint32_t slots = 0;
+        for (DrawDesc& dd : pass.draws) { dd.slot_base = slots; slots += (dd.tri_count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS; }
+        P.total_slots = slots;
         all.insert(all.end(), pass.draws.begin(), pass.draws.end());
         cmd->plan.push_back(P);
+        uint32_t progs = 0;
+        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : 2u;
+        cmd->plan_programs.push_back(progs ? progs : 1u);
         cmd->plan_tris += pass.total_tris;
     }
     if (!all.empty()) {
@@ -887,8 +902,11 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     std::lock_guard<std::mutex> lock(dev->mu);
     for (uint32_t i = 0; i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
-        for (const PassParams& P : c->plan) {
-            HIP_TRY(hipMemsetAsync(P.big_count, 0, 4, dev->stream));
+        for (size_t pi = 0; pi < c->plan.size(); pi++) {
+            PassParams P = c->plan[pi];
+            P.big_count = c->ws.big_counts + c->ws.parity;          // alternate the big-list counter: the raster
+            P.big_count_next = c->ws.big_counts + (c->ws.parity ^ 1u); // kernel zeroes the other one for the next scope
+            c->ws.parity ^= 1u;
             EventPair ev{};
             if (dev->profiling) { mirhi_result r = profile_begin(dev, &ev); if (r != MIRHI_OK) return r; }
             HIP_TRY(launch_geometry(P, dev->stream));
@@ -897,15 +915,10 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
                 dev->pending[MIRHI_KERNEL_GEOMETRY].push_back(ev);
                 mirhi_result r = profile_begin(dev, &ev); if (r != MIRHI_OK) return r;
             }
-            HIP_TRY(launch_raster(P, dev->stream));
+            HIP_TRY(launch_raster(P, c->plan_programs[pi], dev->stream));
             if (dev->profiling) { HIP_TRY(hipEventRecord(ev.b, dev->stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev); }
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += P.total_tris;
-        }
-        if (!c->plan.empty()) {
-            const PassParams& L = c->plan.back();
-            HIP_TRY(hipMemcpyAsync(c->ws.status_host, L.status, 4, hipMemcpyDeviceToHost, dev->stream));
-            HIP_TRY(hipMemcpyAsync(c->ws.status_host + 1, L.big_count, 4, hipMemcpyDeviceToHost, dev->stream));
         }
     }
     if (fence) {

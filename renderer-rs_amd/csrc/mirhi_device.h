@@ -2,7 +2,7 @@
 //
 // Data layout in HBM (see DESIGN.md "Data layout"):
 //   DrawDesc[]   one per recorded draw of a rendering scope (pointers into caller buffers + state)
-//   TileRec[]    per-tile bins: tiles * bin_cap records of 80 B, written by the geometry kernel,
+//   TileRec[]    per-tile bins: tiles * bin_cap records of 48 B, written by the geometry kernel,
 //                consumed by exactly one raster workgroup
 //   BigRec[]     screen-space triangles too large for the bins (or spilled from a full bin);
 //                every raster workgroup scans this list
@@ -16,7 +16,7 @@ constexpr int TILE = 32;              // screen tile edge in pixels (one raster 
 constexpr int TILE_LOG2 = 5;
 constexpr int BLOCK = 8;              // coverage block edge (one wave-iteration covers 8x8 px)
 constexpr int RASTER_THREADS = 256;   // 4 waves; wave q owns the 16x16 quadrant q, 4 px per lane
-constexpr int GEOM_THREADS = 256;
+constexpr int GEOM_THREADS = 64;
 constexpr int MAX_BIN_SPAN = 4;       // triangles spanning more than 4x4 tiles go to the big list
 constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay inside +-2^22 sub-pixels
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
@@ -41,6 +41,7 @@ struct DrawDesc {
     int32_t  vertex_offset;
     uint32_t tri_count;
     uint32_t prim_base;           // global primitive id of triangle 0
+    uint32_t slot_base;           // first geometry-kernel lane of this draw (draws are padded to whole waves)
     uint32_t program;
     uint32_t cull_mode, front_face;
     float    hw, hh, cx, cy;      // viewport half extents and centre
@@ -48,43 +49,28 @@ struct DrawDesc {
     float    gx, gy;              // guard-band plane factors
     int32_t  sx0, sy0, sx1, sy1;  // inclusive scissor (already clamped to render area and extent)
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
-    uint32_t pad[2];
+    uint32_t pad[1];
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");
 
-// One triangle as seen by one 32x32 tile. 20 dwords; the first 16 are read for every triangle.
-struct TileRec {
-    int32_t  Q[3];       // floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
-    int32_t  A0;         // A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23)
-    int32_t  A1, A2, B0, B1;
-    int32_t  B2;
-    float    x0f, y0f;   // snapped vertex 0 in pixels (exact)
-    float    z0;
-    float    zx, zy;     // depth plane
-    uint32_t idk;        // primitive id in tie-break order
-    uint32_t mask;       // bits 0..15: 8x8 blocks of the tile the triangle may touch; bit 31: apply box
-    uint32_t box;        // tile-relative inclusive pixel box minx | maxx<<8 | miny<<16 | maxy<<24
-    uint32_t pad[3];
-};
-static_assert(sizeof(TileRec) == 80, "TileRec is 80 bytes");
-
-// Orientation-normalised snapped triangle in screen space. 16 dwords.
-struct BigRec {
-    int32_t  X0, Y0, X1, Y1, X2, Y2;   // 1/256 px
-    float    z0, zx, zy;
-    uint32_t idk;
-    uint32_t bx;         // pixel bbox minx | maxx<<16 (scissor-clamped, inclusive)
-    uint32_t by;         // miny | maxy<<16
-    uint32_t boxed;      // 1 if the scissor cut the vertex bbox
-    uint32_t pad[3];
-};
-static_assert(sizeof(BigRec) == 64, "BigRec is 64 bytes");
+// Screen-space triangle record, 12 dwords = three 16-byte words.  Written once per overlapped tile into
+// that tile's bin (and once into the big list for triangles that span more than 4x4 tiles, were clipped,
+// or found a bin full); the raster kernel turns it into a tile-relative record in LDS.
+//   w0 = { X0, Y0, X1, Y1 }    snapped vertices, 1/256 px, orientation normalised (interior has E > 0)
+//   w1 = { X2, Y2, z0, zx }    depth of vertex 0 and depth plane d/dx
+//   w2 = { zy, idk, bx, by }   d/dy, primitive id in tie-break order,
+//                              bx = minx | maxx << 16 | boxed << 31, by = miny | maxy << 16 (inclusive pixel box)
+struct TriRec { uint32_t w[12]; };
+static_assert(sizeof(TriRec) == 48, "TriRec is 48 bytes");
+typedef TriRec TileRec;   // bins hold TriRec copies
+typedef TriRec BigRec;    // so does the big list
 
 struct PassParams {
     uint32_t width, height;           // colour target extent
     uint32_t tiles_x, tiles_y;
     uint32_t tile_row_begin, tile_row_end;   // band of tile rows rasterized on this device
     uint32_t num_draws, total_tris;
+    uint32_t total_slots;             // geometry-kernel lanes (every draw padded to a multiple of 64)
     const DrawDesc* draws;
     // depth key (DESIGN.md "Depth key"): zk = (bits(z) ^ zflip) & zmask ; idk = idflip ? MAX-id : id
     uint32_t zflip, zmask, idflip;
@@ -101,7 +87,8 @@ struct PassParams {
     // workspace
     TileRec*  bin_recs; uint32_t* bin_count; uint32_t bin_cap;
     BigRec*   big_recs; uint32_t* big_count; uint32_t big_cap;
-    uint32_t* status;
+    uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
+    uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
 };
 
 }  // namespace mirhi

@@ -56,7 +56,7 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
-__device__ __forceinline__ f3 normalize3(f3 a) { float l = length3(a); return {a.x / l, a.y / l, a.z / l}; }
+__device__ __forceinline__ f3 normalize3(f3 a) { const float inv = 1.0f / sqrtf(dot3(a, a)); return {a.x * inv, a.y * inv, a.z * inv}; }
 __device__ __forceinline__ float saturatef(float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; }
 
 // ------------------------------------------------------------------------------------------------
@@ -83,85 +83,47 @@ __device__ __forceinline__ f4 vs_position(const DrawDesc& D, uint32_t vidx, f3* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared triangle -> tile record
+// screen-space triangle record (TriRec, 48 B) and its tile-relative form (TileRec, 64 B, LDS only)
 // ------------------------------------------------------------------------------------------------
 struct ScreenTri {
     int32_t X[3], Y[3];          // 1/256 px, orientation normalised (interior has E > 0)
     float z0, zx, zy;
-    int32_t minx, maxx, miny, maxy;   // inclusive pixel bbox
+    int32_t minx, maxx, miny, maxy;   // inclusive pixel bbox (scissor-clamped)
     uint32_t idk, boxed;
 };
 
-__device__ __forceinline__ void make_tile_rec(TileRec& r, const ScreenTri& t, int32_t tx, int32_t ty) {
-    const int64_t Ptx = 256 * (int64_t)(tx * TILE) + 128, Pty = 256 * (int64_t)(ty * TILE) + 128;
-    int32_t A[3], B[3], Q[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int a = i, b = (i + 1) % 3;
-        const int32_t dx = t.X[b] - t.X[a], dy = t.Y[b] - t.Y[a];
-        A[i] = -dy; B[i] = dx;
-        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);
-        const int64_t e0 = (int64_t)A[i] * (Ptx - t.X[a]) + (int64_t)B[i] * (Pty - t.Y[a]) + (topleft ? 0 : -1);
-        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r
-        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
-        Q[i] = (int32_t)q;
-    }
-    r.Q[0] = Q[0]; r.Q[1] = Q[1]; r.Q[2] = Q[2];
-    r.A0 = A[0]; r.A1 = A[1]; r.A2 = A[2]; r.B0 = B[0]; r.B1 = B[1]; r.B2 = B[2];
-    r.x0f = (float)t.X[0] * (1.0f / 256.0f);
-    r.y0f = (float)t.Y[0] * (1.0f / 256.0f);
-    r.z0 = t.z0; r.zx = t.zx; r.zy = t.zy;
-    r.idk = t.idk;
-    // tile-relative pixel box and conservative 8x8 block mask
-    const int32_t ox = tx * TILE, oy = ty * TILE;
-    int32_t bx0 = t.minx - ox, bx1 = t.maxx - ox, by0 = t.miny - oy, by1 = t.maxy - oy;
-    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
-    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
-    uint32_t mask = 0;
-#pragma unroll
-    for (int by = 0; by < 4; by++) {
-#pragma unroll
-        for (int bx = 0; bx < 4; bx++) {
-            const int32_t lx = bx * BLOCK, hx = lx + BLOCK - 1, ly = by * BLOCK, hy = ly + BLOCK - 1;
-            bool hit = !(hx < bx0 || lx > bx1 || hy < by0 || ly > by1);
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const int32_t cxp = A[i] >= 0 ? hx : lx, cyp = B[i] >= 0 ? hy : ly;
-                hit = hit && (Q[i] + __mul24(A[i], cxp) + __mul24(B[i], cyp) >= 0);
-            }
-            mask |= hit ? (1u << (by * 4 + bx)) : 0u;
-        }
-    }
-    r.mask = mask | (t.boxed ? 0x80000000u : 0u);
-    r.box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+__device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
+    dst[0] = make_uint4((uint32_t)t.X[0], (uint32_t)t.Y[0], (uint32_t)t.X[1], (uint32_t)t.Y[1]);
+    dst[1] = make_uint4((uint32_t)t.X[2], (uint32_t)t.Y[2], __float_as_uint(t.z0), __float_as_uint(t.zx));
+    dst[2] = make_uint4(__float_as_uint(t.zy), t.idk, (uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.boxed << 31),
+                        (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
 }
 
 // ------------------------------------------------------------------------------------------------
-// a5: screen-space setup of one (possibly clipped) triangle and emission into bins / big list
+// a5: clip-space triangle (all w > 0) -> snapped, culled, oriented screen triangle + depth plane
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit_triangle(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t prim) {
-    ScreenTri t;
+__device__ __forceinline__ bool setup_triangle(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t prim,
+                                               ScreenTri& t) {
     float z[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        if (!(c[i].w > 0.0f)) return;
+        if (!(c[i].w > 0.0f)) return false;
         const float iw = 1.0f / c[i].w;
-        const float xs = (c[i].x * iw) * D.hw + D.cx;
+        const float xs = (c[i].x * iw) * D.hw + D.cx;                     // Vulkan viewport transform
         const float ys = (c[i].y * iw) * D.hh + D.cy;
         const float zs = (c[i].z * iw) * D.dscale + D.dmin;
-        if (!(fabsf(xs) <= 16383.0f) || !(fabsf(ys) <= 16383.0f)) return;
-        t.X[i] = (int32_t)rintf(xs * 256.0f);
+        if (!(fabsf(xs) <= 16383.0f) || !(fabsf(ys) <= 16383.0f)) return false;
+        t.X[i] = (int32_t)rintf(xs * 256.0f);                             // 8 sub-pixel bits, round-half-even
         t.Y[i] = (int32_t)rintf(ys * 256.0f);
         z[i] = zs;
     }
     const int64_t S = (int64_t)(t.X[1] - t.X[0]) * (int64_t)(t.Y[2] - t.Y[0]) -
                       (int64_t)(t.X[2] - t.X[0]) * (int64_t)(t.Y[1] - t.Y[0]);
-    if (S == 0) return;
-    const bool front = (D.front_face == 0) ? (S < 0) : (S > 0);     // Vulkan: a = -S/2, CCW front <=> a > 0
-    if (D.cull_mode == 3) return;
-    if (D.cull_mode == 2 && !front) return;
-    if (D.cull_mode == 1 && front) return;
+    if (S == 0) return false;
+    const bool front = (D.front_face == 0) ? (S < 0) : (S > 0);           // Vulkan: a = -S/2, CCW front <=> a > 0
+    if (D.cull_mode == 3) return false;
+    if (D.cull_mode == 2 && !front) return false;
+    if (D.cull_mode == 1 && front) return false;
     if (S < 0) {
         int32_t ti = t.X[1]; t.X[1] = t.X[2]; t.X[2] = ti;
         ti = t.Y[1]; t.Y[1] = t.Y[2]; t.Y[2] = ti;
@@ -175,57 +137,87 @@ __device__ __forceinline__ void emit_triangle(const PassParams& P, const DrawDes
     t.zx = (dz1 * fy2 - dz2 * fy1) / area;
     t.zy = (dz2 * fx1 - dz1 * fx2) / area;
     t.z0 = z[0];
-    int32_t xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
-    int32_t ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
+    const int32_t xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
+    const int32_t ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
     int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
     int32_t py0 = (ymin + 127) >> 8, py1 = (ymax - 128) >> 8;
     const bool cut = D.scissor_partial && (px0 < D.sx0 || px1 > D.sx1 || py0 < D.sy0 || py1 > D.sy1);
     px0 = max(px0, D.sx0); px1 = min(px1, D.sx1); py0 = max(py0, D.sy0); py1 = min(py1, D.sy1);
-    if (px0 > px1 || py0 > py1) return;
+    if (px0 > px1 || py0 > py1) return false;
+    // tile rows outside this device's band are not rasterized here (tile-row split)
+    const int32_t band0 = (int32_t)P.tile_row_begin * TILE, band1 = (int32_t)P.tile_row_end * TILE - 1;
+    if (py1 < band0 || py0 > band1) return false;
     t.minx = px0; t.maxx = px1; t.miny = py0; t.maxy = py1;
     t.boxed = cut ? 1u : 0u;
     t.idk = P.idflip ? (MAX_PRIM_ID - prim) : prim;
+    return true;
+}
 
-    const int32_t tx0 = px0 >> TILE_LOG2, tx1 = px1 >> TILE_LOG2;
-    int32_t ty0 = py0 >> TILE_LOG2, ty1 = py1 >> TILE_LOG2;
-    ty0 = max(ty0, (int32_t)P.tile_row_begin); ty1 = min(ty1, (int32_t)P.tile_row_end - 1);
-    if (ty0 > ty1) return;
-    bool spill = (tx1 - tx0 >= MAX_BIN_SPAN) || (ty1 - ty0 >= MAX_BIN_SPAN);
-    if (!spill) {
-        for (int32_t ty = ty0; ty <= ty1; ty++) {
-            for (int32_t tx = tx0; tx <= tx1; tx++) {
-                const uint32_t tile = (uint32_t)(ty - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx;
-                const uint32_t slot = atomicAdd(&P.bin_count[tile], 1u);
-                if (slot < P.bin_cap) {
-                    TileRec r;
-                    make_tile_rec(r, t, tx, ty);
-                    uint4* dst = reinterpret_cast<uint4*>(&P.bin_recs[(size_t)tile * P.bin_cap + slot]);
-                    const uint4* src = reinterpret_cast<const uint4*>(&r);
+__device__ __forceinline__ void emit_big(const PassParams& P, const ScreenTri& t) {
+    const uint32_t slot = atomicAdd(P.big_count, 1u);
+    if (slot < P.big_cap) store_tri(reinterpret_cast<uint4*>(P.big_recs) + (size_t)slot * 3u, t);
+    else __hip_atomic_fetch_or(P.status, STATUS_BIG_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Convergent (every lane of the wave calls it, `valid` says whether the lane holds a triangle):
+// copies the triangle record into the bin of each of the <= 4x4 tiles it overlaps.  All returning
+// atomics are issued before the first result is consumed; when every active lane of a slot targets
+// the same tile (the common case for meshes) one lane reserves the whole range.
+__device__ __forceinline__ void bin_triangle(const PassParams& P, bool valid, const ScreenTri& t) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
+    bool spill = false;
+    if (valid) {
+        tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
+        ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
+        nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
+        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
+    }
+    const bool binned = valid && !spill;
+    const uint32_t tile0 = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+    uint32_t raw[MAX_BIN_SPAN * MAX_BIN_SPAN];
+    uint32_t uniform_bits = 0;
 #pragma unroll
-                    for (int k = 0; k < 5; k++) dst[k] = src[k];
-                } else {
-                    spill = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
-                }
+    for (int k = 0; k < MAX_BIN_SPAN * MAX_BIN_SPAN; k++) {
+        const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
+        const bool has = binned && kx < ntx && ky < nty;
+        const uint64_t hm = __ballot(has);
+        raw[k] = 0;
+        if (hm) {
+            const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
+            const int leader = __ffsll((long long)hm) - 1;
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+            const bool uni = __ballot(has && tile == t0) == hm;
+            if (uni) {
+                uniform_bits |= 1u << k;
+                if ((int)lane == leader) raw[k] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(hm));
+            } else if (has) {
+                raw[k] = atomicAdd(&P.bin_count[tile], 1u);
             }
         }
     }
-    if (spill) {
-        const uint32_t slot = atomicAdd(P.big_count, 1u);
-        if (slot < P.big_cap) {
-            BigRec b;
-            b.X0 = t.X[0]; b.Y0 = t.Y[0]; b.X1 = t.X[1]; b.Y1 = t.Y[1]; b.X2 = t.X[2]; b.Y2 = t.Y[2];
-            b.z0 = t.z0; b.zx = t.zx; b.zy = t.zy; b.idk = t.idk;
-            b.bx = (uint32_t)px0 | ((uint32_t)px1 << 16);
-            b.by = (uint32_t)py0 | ((uint32_t)py1 << 16);
-            b.boxed = t.boxed; b.pad[0] = b.pad[1] = b.pad[2] = 0;
-            uint4* dst = reinterpret_cast<uint4*>(&P.big_recs[slot]);
-            const uint4* src = reinterpret_cast<const uint4*>(&b);
 #pragma unroll
-            for (int k = 0; k < 4; k++) dst[k] = src[k];
-        } else {
-            atomicOr(P.status, STATUS_BIG_OVERFLOW);
+    for (int k = 0; k < MAX_BIN_SPAN * MAX_BIN_SPAN; k++) {
+        const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
+        const bool has = binned && kx < ntx && ky < nty;
+        const uint64_t hm = __ballot(has);
+        if (!hm) continue;
+        uint32_t slot = raw[k];
+        if (uniform_bits & (1u << k)) {
+            const int leader = __ffsll((long long)hm) - 1;
+            slot = (uint32_t)__builtin_amdgcn_readlane((int)raw[k], leader) + (uint32_t)__popcll(hm & lt);
+        }
+        if (has) {
+            if (slot < P.bin_cap) {
+                const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
+                store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
+            } else {
+                spill = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
+            }
         }
     }
+    if (valid && spill) emit_big(P, t);
 }
 
 // clip planes: near z>=0, far w-z>=0, guard band x,y within +-g*w (oracle: clip_polygon)
@@ -257,11 +249,15 @@ __device__ __forceinline__ uint32_t outcode_view(f4 c) {
     return oc;
 }
 
-__device__ __noinline__ void clip_and_emit(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t any,
-                                           uint32_t prim) {
-    f4 bufa[12], bufb[12];
-    f4* in = bufa; f4* tmp = bufb;
-    in[0] = c[0]; in[1] = c[1]; in[2] = c[2];
+// Rare path: Sutherland-Hodgman in homogeneous space on a per-lane polygon in LDS (no scratch memory: a
+// kernel that touches scratch pays ~5 us per launch on this part).  Every resulting fan triangle goes to
+// the big list (the raster kernel builds its tile records), so this path needs no binning code.
+constexpr int CLIP_MAX_VERTS = 10;     // 3 + one per plane (near, far, 4 guard-band planes) = 9
+
+__device__ __forceinline__ void clip_and_emit(const PassParams& P, const DrawDesc& D, f4 (*poly)[CLIP_MAX_VERTS],
+                                              f4 c0, f4 c1, f4 c2, uint32_t any, uint32_t prim) {
+    f4* in = poly[0]; f4* tmp = poly[1];
+    in[0] = c0; in[1] = c1; in[2] = c2;
     int n = 3;
     for (int plane = 1; plane <= 32 && n >= 3; plane <<= 1) {
         if (!(any & plane)) continue;
@@ -282,8 +278,9 @@ __device__ __noinline__ void clip_and_emit(const PassParams& P, const DrawDesc& 
         f4* s = in; in = tmp; tmp = s;
     }
     for (int i = 1; i + 1 < n; i++) {
-        const f4 t[3] = {in[0], in[i], in[i + 1]};
-        emit_triangle(P, D, t, prim);
+        const f4 tri[3] = {in[0], in[i], in[i + 1]};
+        ScreenTri t;
+        if (setup_triangle(P, D, tri, prim, t)) emit_big(P, t);
     }
 }
 
@@ -296,24 +293,57 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
     return lo;
 }
 
+// one wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
+// and pipeline-state word) is wave-uniform and lives in SGPRs
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
-    const uint32_t gid = blockIdx.x * GEOM_THREADS + threadIdx.x;
-    if (gid >= P.total_tris) return;
-    const DrawDesc& D = P.draws[find_draw(P, gid)];
-    const uint32_t tri = gid - D.prim_base;
+    __shared__ f4 poly[GEOM_THREADS][2][CLIP_MAX_VERTS];
+    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    uint32_t lo = 0, hi = P.num_draws;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (P.draws[mid].slot_base <= slot0) lo = mid; else hi = mid;
+    }
+    const DrawDesc& D = P.draws[lo];
+    const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
+    const uint32_t prim = D.prim_base + tri;
+    bool valid = false;
+    uint32_t any = 0;
+    ScreenTri t;
     f4 c[3];
+    if (tri < D.tri_count) {
 #pragma unroll
-    for (uint32_t k = 0; k < 3; k++) c[k] = vs_position(D, fetch_index(D, 3u * tri + k), nullptr);
-    const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
-    if (o0 & o1 & o2) return;
-    const uint32_t any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
-    if (any == 0) emit_triangle(P, D, c, gid);
-    else clip_and_emit(P, D, c, any, gid);
+        for (uint32_t k = 0; k < 3; k++) c[k] = vs_position(D, fetch_index(D, 3u * tri + k), nullptr);
+        const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
+        if (!(o0 & o1 & o2)) {
+            any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
+            if (any == 0) valid = setup_triangle(P, D, c, prim, t);
+        }
+    }
+    bin_triangle(P, valid, t);
+    if (any) clip_and_emit(P, D, poly[threadIdx.x], c[0], c[1], c[2], any, prim);
 }
 
 // ------------------------------------------------------------------------------------------------
-// a8: fragment programs (shading is tolerance-checked, |dRGB| < 1e-4, not bit-exact)
+// a8: fragment programs.  Colour is tolerance-checked (|dRGB| < 1e-4 vs the oracle), not bit-exact, so
+// this part may contract to FMA and use the 1-ulp hardware rcp / rsq / exp2 / log2.
 // ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// pow(x, y) for x >= 0 as exp2(y * log2(x)) (HLSL pow lowering); pow(0, y>0) = 0
+// log2 near 1 comes from the series of ln(1+t) (t = x-1 is exact there): the hardware v_log_f32 has an absolute
+// error of ~2^-22 around 1, which a Blinn-Phong exponent of up to 2048 would amplify past the 1e-4 colour bound.
+__device__ __forceinline__ float flog2(float x) {
+    const float t = x - 1.0f;
+    const float p = t * (1.0f + t * (-0.5f + t * (0.33333334f + t * (-0.25f + t * 0.2f))));
+    return fabsf(t) < 0.015625f ? p * 1.44269504089f : __builtin_amdgcn_logf(x);
+}
+__device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgcn_exp2f(y * flog2(x)); }
+__device__ __forceinline__ f3 fnormalize3(f3 a) { const float r = frsq(dot3(a, a)); return {a.x * r, a.y * r, a.z * r}; }
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ float attenuation(float distance, float radius) {          // lights.hlsli:63-73
     const float att = 1.0f / (distance * distance + 1.0f);
     float falloff = saturatef(1.0f - distance / radius);
@@ -332,7 +362,7 @@ __device__ __forceinline__ f3 blinn_phong(f3 L, f3 V, f3 N, f3 lightColor, f3 al
     const f3 H = normalize3(add3(L, V));
     float NdotH = dot3(N, H);
     if (!(NdotH > 0.0f)) NdotH = 0.0f;
-    const float sp = powf(NdotH, shininess);
+    const float sp = fpow(NdotH, shininess);
     return add3(diffuse, scale3(lightColor, sp));
 }
 
@@ -346,6 +376,7 @@ __device__ __forceinline__ f4 texel(const uint8_t* tex, int32_t w, int32_t h, in
 // bilinear, repeat, no mips (see oracle sample_bilinear)
 __device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, uint32_t h, float u, float v) {
     if (!tex || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
+    if (w == 1 && h == 1) return texel(tex, 1, 1, 0, 0);
     const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float ax = fx - x0f, ay = fy - y0f;
@@ -359,6 +390,9 @@ __device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, ui
     return r;
 }
 
+#pragma clang fp contract(off)
+// Everything that feeds pow(NdotH, shininess) must match the oracle bit for bit: an exponent of up to 2048
+// turns a 1-ulp difference in NdotH into a 1e-4 relative difference of the specular term.
 struct Varyings { f3 world, normal, tangent, bitangent; float u, v; };
 
 __device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
@@ -367,6 +401,7 @@ __device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
 }
 
 // perspective-correct barycentrics of the pixel centre from the original clip-space triangle
+// (2-D homogeneous form relative to the pixel: valid for w <= 0 vertices, no clipped attributes needed)
 __device__ __forceinline__ void barycentrics(const DrawDesc& D, const f4 c[3], float pxc, float pyc, float b[3]) {
     float ax[3], ay[3];
 #pragma unroll
@@ -396,8 +431,9 @@ __device__ __forceinline__ f4 shade_triangle_program(const DrawDesc& D, uint32_t
     return {o.x, o.y, o.z, 1.0f};
 }
 
-__device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
+__device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; Varyings vv[3];
+    const bool full = D.program == 2;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         const uint32_t vidx = fetch_index(D, 3u * tri + k);
@@ -405,14 +441,16 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
         f3 world;
         c[k] = vs_position(D, vidx, &world);
         const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
-        const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
-        const float tw = ldf(v, 44);
-        const f3 N = normalize3(mat3_mul(D.object + 16, n));                 // vertex/model.hlsl:51
-        f3 T = normalize3(mat3_mul(D.object, t));                            // :52
-        T = normalize3(sub3(T, scale3(N, dot3(T, N))));                      // :55
-        const f3 B = scale3(cross3(N, T), tw);                               // :58
-        vv[k].world = world; vv[k].normal = N; vv[k].tangent = T; vv[k].bitangent = B;
-        vv[k].u = ldf(v, 24); vv[k].v = ldf(v, 28);
+        const f3 N = normalize3(mat3_mul(D.object + 16, n));                // vertex/model.hlsl:51
+        vv[k].world = world; vv[k].normal = N;
+        if (full) {
+            const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
+            const float tw = ldf(v, 44);
+            f3 T = normalize3(mat3_mul(D.object, t));                       // :52
+            T = normalize3(sub3(T, scale3(N, dot3(T, N))));                 // :55
+            vv[k].tangent = T; vv[k].bitangent = scale3(cross3(N, T), tw);   // :58
+            vv[k].u = ldf(v, 24); vv[k].v = ldf(v, 28);
+        }
     }
     float b[3];
     barycentrics(D, c, pxc, pyc, b);
@@ -420,14 +458,14 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
     const f3 Nv = interp3(b, vv[0].normal, vv[1].normal, vv[2].normal);
     const f3 camPos = {D.camera[48], D.camera[49], D.camera[50]};          // cameraPosition @192 B
     const f3 V = normalize3(sub3(camPos, worldPos));
+    f3 N = normalize3(Nv);
 
-    if (D.program == 1) {                                                    // pixel/model.hlsl:29-82
+    if (!full) {                                                             // pixel/model.hlsl:29-82
         const f3 albedo = {0.7f, 0.7f, 0.7f};
         const f3 one = {1.0f, 1.0f, 1.0f};
         const f3 L = normalize3(one);
-        const f3 N = normalize3(Nv);
         const f3 ambient = scale3(scale3(albedo, 0.03f), 1.0f);
-        const f3 lighting = blinn_phong(L, V, N, scale3(one, 1.0f), albedo, roughness_to_shininess(0.5f));
+        const f3 lighting = blinn_phong(L, V, N, one, albedo, roughness_to_shininess(0.5f));
         const f3 col = add3(ambient, lighting);
         return {col.x, col.y, col.z, 1.0f};
     }
@@ -440,8 +478,7 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
     const f3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
     const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
     const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
-    const bool hasNormalMap = length3(ncm1) > 0.01f;                         // :94-95
-    f3 N = normalize3(Nv);
+    const bool hasNormalMap = length3(ncm1) > 0.01f;                          // :94-95
     if (hasNormalMap) {                                                      // GetWorldNormal :63-83
         const f3 ns = {nc.x * 2.0f - 1.0f, nc.y * 2.0f - 1.0f, nc.z * 2.0f - 1.0f};
         const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
@@ -468,7 +505,7 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
         const float intensity = ldf(Lp, 28);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = {lv.x / dist, lv.y / dist, lv.z / dist};
+        const f3 L = scale3(lv, 1.0f / dist);
         const f3 lc = scale3(scale3(color, intensity), attenuation(dist, radius));
         lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
     }
@@ -482,7 +519,7 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
         const float intensity = ldf(Ls, 44);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = {lv.x / dist, lv.y / dist, lv.z / dist};
+        const f3 L = scale3(lv, 1.0f / dist);
         const float datt = attenuation(dist, 50.0f);
         const f3 sd = normalize3(sdir);
         const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);                // CalculateSpotAttenuation :77-81
@@ -494,10 +531,11 @@ __device__ __noinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, 
     return {col.x, col.y, col.z, albedoSample.w * baseColor.w};
 }
 
+#pragma clang fp contract(fast)
 // a9: sRGB OETF + UNORM8, BGRA byte order (swapchain.rs:561-570)
 __device__ __forceinline__ uint32_t srgb8(float c) {
     c = saturatef(c);
-    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * fpow(c, 1.0f / 2.4f) - 0.055f;
     e = saturatef(e);
     return (uint32_t)rintf(e * 255.0f);
 }
@@ -505,54 +543,140 @@ __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c) {
     return srgb8(c.z) | (srgb8(c.y) << 8) | (srgb8(c.x) << 16) | ((uint32_t)rintf(saturatef(c.w) * 255.0f) << 24);
 }
 
+#pragma clang fp contract(off)
+
 // ------------------------------------------------------------------------------------------------
 // raster kernel
 // ------------------------------------------------------------------------------------------------
 struct PixelState { uint32_t zk[4], idk[4]; };
+struct RecRegs { uint4 w0, w1, w2, w3; };
 
-__device__ __forceinline__ void raster_chunk(const TileRec* __restrict__ lds, uint32_t n, uint32_t qmask,
-                                             int32_t ix0, int32_t iy0, float pxc0, float pyc0, const PassParams& P,
-                                             PixelState& st, uint32_t qbit0) {
-    for (uint32_t j = 0; j < n; j++) {
-        const uint32_t m = __builtin_amdgcn_readfirstlane(lds[j].mask);
-        if (!(m & qmask)) continue;
-        const uint4 w0 = reinterpret_cast<const uint4*>(&lds[j])[0];
-        const uint4 w1 = reinterpret_cast<const uint4*>(&lds[j])[1];
-        const uint4 w2 = reinterpret_cast<const uint4*>(&lds[j])[2];
-        const uint4 w3 = reinterpret_cast<const uint4*>(&lds[j])[3];
-        const int32_t Q0 = (int32_t)w0.x, Q1 = (int32_t)w0.y, Q2 = (int32_t)w0.z;
-        const int32_t A0 = (int32_t)w0.w, A1 = (int32_t)w1.x, A2 = (int32_t)w1.y;
-        const int32_t B0 = (int32_t)w1.z, B1 = (int32_t)w1.w, B2 = (int32_t)w2.x;
-        const float x0f = __uint_as_float(w2.y), y0f = __uint_as_float(w2.z), z0 = __uint_as_float(w2.w);
-        const float zx = __uint_as_float(w3.x), zy = __uint_as_float(w3.y);
-        const uint32_t idk = w3.z;
-        const int32_t s0 = Q0 + __mul24(A0, ix0) + __mul24(B0, iy0);
-        const int32_t s1 = Q1 + __mul24(A1, ix0) + __mul24(B1, iy0);
-        const int32_t s2 = Q2 + __mul24(A2, ix0) + __mul24(B2, iy0);
-        uint32_t box = 0;
-        const bool boxed = (m & 0x80000000u) != 0;
-        if (boxed) box = lds[j].box;
+__device__ __forceinline__ RecRegs load_rec(const uint4* lds_rec, uint32_t j) {
+    RecRegs r;
+    r.w0 = lds_rec[j * 4u + 0]; r.w1 = lds_rec[j * 4u + 1]; r.w2 = lds_rec[j * 4u + 2]; r.w3 = lds_rec[j * 4u + 3];
+    return r;
+}
+
+// 48-bit product of two signed 24-bit values
+__device__ __forceinline__ int64_t mul24x24(int32_t a, int32_t b) {
+    const uint32_t lo = (uint32_t)__mul24(a, b);     // low 32 bits of the product (operands fit 24 bits)
+    const int32_t hi = __mulhi(a, b);                // high 32 bits of the 64-bit product
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | lo);
+}
+
+// TriRec (screen space) -> TileRec for tile (tx, ty); false if no 8x8 block of the tile can be touched.
+//   w0 = { Q0, Q1, Q2, A0 }   Q_i = floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
+//   w1 = { A1, A2, B0, B1 }   A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23, fits v_mad_i32_i24)
+//   w2 = { B2, dxt, dyt, z0 } (tile origin pixel centre) - (snapped vertex 0), in pixels (exact), vertex-0 depth
+//   w3 = { zx, zy, idk, mask } mask bits 0..15 = 8x8 blocks the triangle may touch, bit 31 = pixel box applies
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2,
+                                              int32_t tx, int32_t ty) {
+    const int32_t X[3] = {(int32_t)w0.x, (int32_t)w0.z, (int32_t)w1.x}, Y[3] = {(int32_t)w0.y, (int32_t)w0.w, (int32_t)w1.y};
+    const int32_t ox = tx * TILE, oy = ty * TILE;
+    const int32_t Ptx = 256 * ox + 128, Pty = 256 * oy + 128;           // tile origin pixel centre, 1/256 px
+    int32_t A[3], B[3], Q[3];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int bx = b & 1, by = b >> 1;
-            if (!(m & (qbit0 << (by * 4 + bx)))) continue;
-            const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK;
-            const int32_t S1 = s1 + (A1 * bx + B1 * by) * BLOCK;
-            const int32_t S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
-            bool inside = (S0 | S1 | S2) >= 0;
-            if (boxed) {
-                const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
-                inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
-                         iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
-            }
-            const float dx = (pxc0 + (float)(bx * BLOCK)) - x0f;
-            const float dy = (pyc0 + (float)(by * BLOCK)) - y0f;
-            float z = (z0 + dx * zx) + dy * zy;
-            z = z > 0.0f ? (z < 1.0f ? z : 1.0f) : 0.0f;
-            const uint32_t zk = (__float_as_uint(z) ^ P.zflip) & P.zmask;
-            const uint64_t key = ((uint64_t)zk << 32) | idk;
-            const uint64_t cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
-            if (inside && key < cur) { st.zk[b] = zk; st.idk[b] = idk; }
+    for (int i = 0; i < 3; i++) {
+        const int a = i, b = (i + 1) % 3;
+        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
+        A[i] = -dy; B[i] = dx;
+        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
+        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22, |Pt| < 2^21)
+        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
+        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
+        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
+        Q[i] = (int32_t)q;
+    }
+    int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - ox, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - ox;
+    int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - oy, by1 = (int32_t)(w2.w >> 16) - oy;
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
+    // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
+    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).
+    int32_t c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
+    uint32_t mask = 0;
+#pragma unroll 1
+    for (int by = 0; by < 4; by++) {
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) {
+            const int32_t lx = bx * BLOCK, hx = lx + BLOCK - 1, ly = by * BLOCK, hy = ly + BLOCK - 1;
+            bool hit = !(hx < bx0 || lx > bx1 || hy < by0 || ly > by1);
+            hit = hit && ((c[0] + A[0] * (bx * BLOCK)) | (c[1] + A[1] * (bx * BLOCK)) | (c[2] + A[2] * (bx * BLOCK))) >= 0;
+            mask |= hit ? (1u << (by * 4 + bx)) : 0u;
+        }
+        c[0] += B[0] * BLOCK; c[1] += B[1] * BLOCK; c[2] += B[2] * BLOCK;
+    }
+    const float inv256 = 1.0f / 256.0f;
+    const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
+    const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
+    out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
+    out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
+    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), w1.z);
+    out[3] = make_uint4(w1.w, w2.x, w2.y, mask | (w2.z & 0x80000000u));
+    box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+    return mask != 0;
+}
+
+// coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
+// KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied).
+template <int KEYED>
+__device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
+                                              float fiy0, const PassParams& P, PixelState& st, uint32_t qbit0) {
+    const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
+    const int32_t B0 = (int32_t)r.w1.z, B1 = (int32_t)r.w1.w, B2 = (int32_t)r.w2.x;
+    const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
+    const uint32_t idk = r.w3.z;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(r.w3.w);
+    const int32_t s0 = (int32_t)r.w0.x + __mul24(A0, ix0) + __mul24(B0, iy0);
+    const int32_t s1 = (int32_t)r.w0.y + __mul24(A1, ix0) + __mul24(B1, iy0);
+    const int32_t s2 = (int32_t)r.w0.z + __mul24(A2, ix0) + __mul24(B2, iy0);
+    // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
+    const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
+    const bool boxed = (m & 0x80000000u) != 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int bx = b & 1, by = b >> 1;
+        if (!(m & (qbit0 << (by * 4 + bx)))) continue;
+        const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK;
+        const int32_t S1 = s1 + (A1 * bx + B1 * by) * BLOCK;
+        const int32_t S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
+        bool inside = (S0 | S1 | S2) >= 0;
+        if (boxed) {
+            const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
+            inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
+                     iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
+        }
+        const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
+        float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+        z = z > 0.0f ? (z < 1.0f ? z : 1.0f) : 0.0f;
+        uint32_t zk = __float_as_uint(z);
+        if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+        const uint64_t key = ((uint64_t)zk << 32) | idk;
+        const uint64_t cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+        if (inside && key < cur) { st.zk[b] = zk; st.idk[b] = idk; }
+    }
+}
+
+// all records of an LDS chunk: per 64 records one ballot builds the bitmap of records that touch this
+// wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
+template <int KEYED>
+__device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
+                                             int32_t ix0, int32_t iy0, float fix0, float fiy0, const PassParams& P,
+                                             PixelState& st, uint32_t qbit0, uint32_t lane) {
+    for (uint32_t g = 0; g < n; g += 64u) {
+        const uint32_t j = g + lane;
+        const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
+        uint64_t bits = __ballot((mymask & qmask) != 0u);
+        if (!bits) continue;
+        while (bits) {
+            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
+            bits &= bits - 1;
+            const RecRegs cur = load_rec(lds_rec, cur_j);
+            uint32_t box = 0;
+            if (__builtin_amdgcn_readfirstlane(cur.w3.w) & 0x80000000u) box = lds_box[cur_j];
+            raster_record<KEYED>(cur, box, ix0, iy0, fix0, fiy0, P, st, qbit0);
         }
     }
 }
@@ -572,18 +696,66 @@ __device__ __forceinline__ void init_key(const PassParams& P, uint32_t px, uint3
     }
 }
 
-__global__ __launch_bounds__(RASTER_THREADS) void raster_kernel(const PassParams P) {
-    __shared__ TileRec lds[RASTER_THREADS];
+// Stages up to RASTER_THREADS triangle records of `list` (bin or big list) into LDS as tile records
+// (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
+template <int KEYED>
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec,
+                                            uint32_t* lds_box, uint32_t* lds_count, uint32_t tx, uint32_t ty,
+                                            uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
+                                            const PassParams& P, PixelState& st, uint32_t qbit0, uint32_t tid,
+                                            uint32_t lane) {
+    const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
+    for (uint32_t base = 0; base < n_total; base += RASTER_THREADS) {
+        if (tid == 0) *lds_count = 0;
+        __syncthreads();
+        const uint32_t i = base + tid;
+        bool hit = false;
+        uint4 rec[4]; uint32_t box = 0;
+        if (i < n_total) {
+            const uint4 w2 = list[(size_t)i * 3u + 2u];
+            const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
+            const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
+            hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
+            if (hit) hit = make_tile_rec(rec, box, list[(size_t)i * 3u], list[(size_t)i * 3u + 1u], w2, (int32_t)tx, (int32_t)ty);
+        }
+        const uint64_t ball = __ballot(hit);
+        uint32_t wbase = 0;
+        if (lane == 0 && ball) wbase = atomicAdd(lds_count, (uint32_t)__popcll(ball));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (hit) {
+            const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+            lds_rec[slot * 4u + 0] = rec[0]; lds_rec[slot * 4u + 1] = rec[1];
+            lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
+            lds_box[slot] = box;
+        }
+        __syncthreads();
+        const uint32_t n = *lds_count;
+        if (n) raster_chunk<KEYED>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
+    }
+}
+
+// PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws
+template <int PROGS, int KEYED>
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PROGS == 2 ? 4 : 3))) void raster_kernel(const PassParams P) {
+    __shared__ uint4 lds_rec[RASTER_THREADS * 4];
+    __shared__ uint32_t lds_box[RASTER_THREADS];
     __shared__ uint32_t lds_count;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, q = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % P.tiles_x, ty = P.tile_row_begin + tile / P.tiles_x;
     const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
     const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
-    const float pxc0 = (float)px0 + 0.5f, pyc0 = (float)py0 + 0.5f;
+    const float fix0 = (float)ix0, fiy0 = (float)iy0;
     // the four 8x8 blocks of quadrant q are bits (2*(q>>1)+by)*4 + 2*(q&1)+bx of the record's block mask
     const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
     const uint32_t qmask = qbit0 * 0x33u;
+
+    // both counters are fetched up front so their latencies overlap
+    const uint32_t count_raw = P.bin_count[tile];
+    const uint32_t nbig_raw = *P.big_count;
+    const uint32_t count = count_raw < P.bin_cap ? count_raw : P.bin_cap;
+    const uint32_t nbig = nbig_raw < P.big_cap ? nbig_raw : P.big_cap;
 
     PixelState st;
 #pragma unroll
@@ -593,93 +765,56 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_kernel(const PassParams
         init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
     }
 
-    // ---- per-tile bin -------------------------------------------------------------------------
-    if (tid == 0) {
-        const uint32_t c = P.bin_count[tile];
-        lds_count = c < P.bin_cap ? c : P.bin_cap;
-        P.bin_count[tile] = 0;                       // ready for the next scope that uses this workspace
+    if (count) {
+        raster_list<KEYED>(reinterpret_cast<const uint4*>(P.bin_recs) + (size_t)tile * P.bin_cap * 3u, count, lds_rec, lds_box,
+                           &lds_count, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
+        if (tid == 0) P.bin_count[tile] = 0;            // ready for the next scope that uses this workspace
     }
-    __syncthreads();
-    const uint32_t count = lds_count;
-    const uint4* bin = reinterpret_cast<const uint4*>(P.bin_recs + (size_t)tile * P.bin_cap);
-    for (uint32_t base = 0; base < count; base += RASTER_THREADS) {
-        const uint32_t n = min((uint32_t)RASTER_THREADS, count - base);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (uint32_t e = tid; e < n * 5u; e += RASTER_THREADS) dst[e] = bin[(size_t)base * 5u + e];
-        __syncthreads();
-        raster_chunk(lds, n, qmask, ix0, iy0, pxc0, pyc0, P, st, qbit0);
-        __syncthreads();
+    if (tile == 0 && tid == 0) {
+        *P.big_count_next = 0;                          // the next scope on this workspace appends to the other counter
+        P.status[1] = nbig_raw;
     }
-
-    // ---- big list: every tile tests every large / spilled triangle ------------------------------
-    const uint32_t nbig_raw = *P.big_count;
-    const uint32_t nbig = nbig_raw < P.big_cap ? nbig_raw : P.big_cap;
-    const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
-    for (uint32_t base = 0; base < nbig; base += RASTER_THREADS) {
-        if (tid == 0) lds_count = 0;
-        __syncthreads();
-        const uint32_t i = base + tid;
-        bool hit = false;
-        ScreenTri t;
-        if (i < nbig) {
-            const uint4* src = reinterpret_cast<const uint4*>(&P.big_recs[i]);
-            const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-            t.minx = (int32_t)(w2.z & 0xFFFFu); t.maxx = (int32_t)(w2.z >> 16);
-            t.miny = (int32_t)(w2.w & 0xFFFFu); t.maxy = (int32_t)(w2.w >> 16);
-            hit = !(t.maxx < tpx0 || t.minx > tpx0 + TILE - 1 || t.maxy < tpy0 || t.miny > tpy0 + TILE - 1);
-            t.X[0] = (int32_t)w0.x; t.Y[0] = (int32_t)w0.y; t.X[1] = (int32_t)w0.z; t.Y[1] = (int32_t)w0.w;
-            t.X[2] = (int32_t)w1.x; t.Y[2] = (int32_t)w1.y;
-            t.z0 = __uint_as_float(w1.z); t.zx = __uint_as_float(w1.w); t.zy = __uint_as_float(w2.x);
-            t.idk = w2.y; t.boxed = w3.x;
-        }
-        TileRec r;
-        if (hit) {
-            make_tile_rec(r, t, (int32_t)tx, (int32_t)ty);
-            hit = (r.mask & 0xFFFFu) != 0;
-        }
-        // wave-level compaction: ballot + prefix popcount, one LDS atomic per wave
-        const uint64_t ball = __ballot(hit);
-        uint32_t wbase = 0;
-        if (lane == 0 && ball) wbase = atomicAdd(&lds_count, (uint32_t)__popcll(ball));
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (hit) {
-            const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
-            uint4* dst = reinterpret_cast<uint4*>(&lds[slot]);
-            const uint4* src = reinterpret_cast<const uint4*>(&r);
-#pragma unroll
-            for (int k = 0; k < 5; k++) dst[k] = src[k];
-        }
-        __syncthreads();
-        const uint32_t n = lds_count;
-        if (n) raster_chunk(lds, n, qmask, ix0, iy0, pxc0, pyc0, P, st, qbit0);
-        __syncthreads();
-    }
+    if (nbig)    // every tile tests every large / clipped / spilled triangle
+        raster_list<KEYED>(reinterpret_cast<const uint4*>(P.big_recs), nbig, lds_rec, lds_box, &lds_count, tx, ty, qmask, ix0,
+                           iy0, fix0, fiy0, P, st, qbit0, tid, lane);
 
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
-#pragma unroll
+#pragma unroll 1
     for (int b = 0; b < 4; b++) {
         const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
-        if (px >= P.width || py >= P.height) continue;
+        const bool inb = px < P.width && py < P.height;
         uint32_t izk, iidk, zorig;
-        init_key(P, px, py, true, izk, iidk, zorig);
-        const bool none = (st.zk[b] == izk) && (st.idk[b] == iidk);
+        init_key(P, px, py, inb, izk, iidk, zorig);
+        const uint32_t zkb = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
+        const uint32_t idb = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
+        const bool none = !inb || ((zkb == izk) && (idb == iidk));
         const size_t pix = (size_t)py * P.width + px;
-        uint32_t prim = NO_PRIM;
+        const uint32_t prim = none ? NO_PRIM : (P.idflip ? (MAX_PRIM_ID - idb) : idb);
         f4 col = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
-        if (!none) {
-            prim = P.idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b];
-            const DrawDesc& D = P.draws[find_draw(P, prim)];
-            const uint32_t tri = prim - D.prim_base;
-            const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
-            col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program(D, tri, pxc, pyc);
+        // waterfall over the draws present in this wave: the draw descriptor stays wave-uniform (scalar loads)
+        const uint32_t mydraw = none ? 0xFFFFFFFFu : (P.num_draws > 1 ? find_draw(P, prim) : 0u);
+        uint64_t todo = __ballot(!none);
+        while (todo) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);
+            const bool mine = mydraw == d;
+            if (mine) {
+                const DrawDesc& D = P.draws[d];
+                const uint32_t tri = prim - D.prim_base;
+                const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
+                if (PROGS == 1) col = shade_triangle_program(D, tri, pxc, pyc);
+                else if (PROGS == 2) col = shade_model_program(D, tri, pxc, pyc);
+                else col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program(D, tri, pxc, pyc);
+            }
+            todo &= ~__ballot(mine);
         }
+        if (!inb) continue;
         if (!(none && P.color_load)) {
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
             else reinterpret_cast<uint32_t*>(P.color)[pix] = pack_bgra8_srgb(col);
         }
         if (P.prim_out) P.prim_out[pix] = prim;
         if (P.depth && P.depth_store) {
-            const uint32_t zb = (none || !P.zmask) ? zorig : (st.zk[b] ^ P.zflip);
+            const uint32_t zb = (none || !P.zmask) ? zorig : (zkb ^ P.zflip);
             P.depth[pix] = __uint_as_float(zb);
         }
     }
@@ -689,16 +824,27 @@ __global__ __launch_bounds__(RASTER_THREADS) void raster_kernel(const PassParams
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_geometry(const PassParams& P, hipStream_t stream) {
-    if (P.total_tris == 0) return hipSuccess;
-    const uint32_t blocks = (P.total_tris + GEOM_THREADS - 1) / GEOM_THREADS;
+    if (P.total_slots == 0) return hipSuccess;
+    const uint32_t blocks = P.total_slots / GEOM_THREADS;
     hipLaunchKernelGGL(geometry_kernel, dim3(blocks), dim3(GEOM_THREADS), 0, stream, P);
     return hipGetLastError();
 }
 
-hipError_t launch_raster(const PassParams& P, hipStream_t stream) {
+template <int KEYED>
+static void launch_raster_k(const PassParams& P, uint32_t programs, dim3 grid, hipStream_t stream) {
+    const dim3 block(RASTER_THREADS);
+    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED>), grid, block, 0, stream, P);
+    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((raster_kernel<1, KEYED>), grid, block, 0, stream, P);
+}
+
+hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t stream) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
-    hipLaunchKernelGGL(raster_kernel, dim3(P.tiles_x * rows), dim3(RASTER_THREADS), 0, stream, P);
+    const dim3 grid(P.tiles_x * rows);
+    // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
+    if (P.zflip == 0u && P.zmask == 0xFFFFFFFFu) launch_raster_k<0>(P, programs, grid, stream);
+    else launch_raster_k<1>(P, programs, grid, stream);
     return hipGetLastError();
 }
 

@@ -1,0 +1,55 @@
+"""Screen-tile-row split across the GPUs of one node.
+
+Each rank owns a contiguous band of 32-pixel tile rows (the last rank's band may be short), renders
+only that band (mirhi_device_set_tile_split) and the bands are exchanged with ONE all-gather of
+the final RGBA rows -- only when the split is enabled; the 1-GPU path never touches
+torch.distributed.  The frame buffer is allocated with `padded_rows` rows so every rank's slice
+has the same size and the all-gather runs in place (input = output slice of this rank).
+"""
+from __future__ import annotations
+
+TILE = 32
+
+
+def tiles_y(height: int) -> int:
+    return (height + TILE - 1) // TILE
+
+
+def band_tile_rows(height: int, rank: int, world: int):
+    """Same formula as band_tile_rows() in csrc/mirhi_api.hip."""
+    ty = tiles_y(height)
+    per = (ty + world - 1) // world
+    b = min(rank * per, ty)
+    e = min(b + per, ty)
+    return b, e
+
+
+def band_rows(height: int, rank: int, world: int):
+    b, e = band_tile_rows(height, rank, world)
+    return min(b * TILE, height), min(e * TILE, height)
+
+
+def rows_per_rank(height: int, world: int) -> int:
+    return ((tiles_y(height) + world - 1) // world) * TILE
+
+
+def padded_rows(height: int, world: int) -> int:
+    return rows_per_rank(height, world) * world
+
+
+def all_gather_bands(frame, rank: int, world: int, group=None):
+    """In-place all-gather of the row bands. `frame` is a (padded_rows, W, C) tensor (any device);
+    rank r has rendered rows [r*per, (r+1)*per) and receives everyone else's."""
+    import torch.distributed as dist
+    per = frame.shape[0] // world
+    assert per * world == frame.shape[0], "frame must have padded_rows(height, world) rows"
+    mine = frame[rank * per:(rank + 1) * per]
+    if frame.is_cuda:
+        dist.all_gather_into_tensor(frame, mine, group=group)
+    else:  # gloo (CPU tests): list form
+        chunks = [frame[r * per:(r + 1) * per] for r in range(world)]
+        outs = [c.clone() for c in chunks]
+        dist.all_gather(outs, mine.contiguous(), group=group)
+        for c, o in zip(chunks, outs):
+            c.copy_(o)
+    return frame
