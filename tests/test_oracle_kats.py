@@ -1,0 +1,189 @@
+"""Pins the CPU oracle against every known answer the reference holds for the hot path
+(tests/golden/kats.json, produced by tools/make_kats.py from the reference checkout)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+
+
+def test_k2_hello_triangle_coverage_256(oracle, scenes):
+    """Analytic coverage under the Vulkan top-left rule (crates/renderer/src/renderer.rs:242-246 vertices)."""
+    k = KATS["K2_hello_coverage_256"]
+    r = oracle.render(scenes.hello_triangle(256, 256))
+    cov = r["prim"] != 0xFFFFFFFF
+    assert int(cov.sum()) == k["covered_pixels"] == 8192
+    rows = np.where(cov.any(axis=1))[0]
+    assert rows.min() == k["first_row"] and rows.max() == k["last_row"]
+    assert list(np.where(cov[65])[0]) == k["row65"]
+    xs = np.where(cov[191])[0]
+    assert [int(xs.min()), int(xs.max())] == k["row191_range"]
+    for y, n in k["row_counts"].items():
+        assert int(cov[int(y)].sum()) == n
+    # clear colour elsewhere (renderer.rs:484-488), alpha 1
+    assert np.allclose(r["rgba"][0, 0], [0.1, 0.1, 0.15, 1.0])
+    # centroid colour = (1/3,1/3,1/3): smooth perspective-correct interpolation with w = 1
+    cy, cx = 149, 128   # centroid of (128,64),(64,192),(192,192) is (128, 149.33)
+    assert np.allclose(r["rgba"][cy, cx, :3].sum(), 1.0, atol=1e-6)
+
+
+def test_k1_screenshot_statistics(oracle, scenes):
+    """The only golden render: screenshots/Hello Triangle.png (sRGB swapchain, crates/rhi/src/swapchain.rs:561-570)."""
+    k = KATS["K1_screenshot"]
+    w, h = k["client_size"]
+    r = oracle.render(scenes.hello_triangle(w, h))
+    rgb = r["bgra8"][:, :, [2, 1, 0]].astype(np.int32)
+    assert rgb[h - 5, 5].tolist() == k["background_srgb8"]          # sRGB8 of linear (0.1, 0.1, 0.15)
+    cov = r["prim"] != 0xFFFFFFFF
+    ys, xs = np.where(cov)
+    assert abs(int(xs.min()) - k["triangle_bbox_x"][0]) <= 2 and abs(int(xs.max()) - k["triangle_bbox_x"][1]) <= 2
+    assert abs(int(ys.min()) - k["triangle_bbox_y_client"][0]) <= 2 and abs(int(ys.max()) - k["triangle_bbox_y_client"][1]) <= 2
+    assert abs(int(cov.sum()) - k["covered_pixels"]) / k["covered_pixels"] < 0.005
+    cx, cy = k["centroid_client"]
+    assert np.abs(rgb[cy, cx] - np.array(k["centroid_srgb8"])).max() <= 2
+    # red vertex at the top (no Y inversion in the shader), green bottom-left, blue bottom-right
+    top = rgb[int(ys.min()) + 3, int(round(xs[ys == ys.min() + 3].mean()))]
+    assert np.abs(top - np.array(k["top_row_rgb"])).max() <= 6 and top.argmax() == 0
+    bl = rgb[int(ys.max()) - 3, int(xs[ys == ys.max() - 3].min()) + 8]
+    br = rgb[int(ys.max()) - 3, int(xs[ys == ys.max() - 3].max()) - 8]
+    assert np.abs(bl - np.array(k["bottom_left_rgb"])).max() <= 6 and bl.argmax() == 1
+    assert np.abs(br - np.array(k["bottom_right_rgb"])).max() <= 6 and br.argmax() == 2
+
+
+def test_k3_shader_constants(oracle):
+    """lights.hlsli:63-73,152-159 and the fallback constants of pixel/model.hlsl:36-43,60."""
+    k = KATS["K3_shader_constants"]
+    L = oracle.lib()
+    for d, rad, want in k["attenuation"]:
+        assert L.oracle_attenuation(d, rad) == pytest.approx(want, abs=1e-6)
+    for r, want in k["roughness_to_shininess"]:
+        assert L.oracle_roughness_to_shininess(r) == want
+    assert L.oracle_roughness_to_shininess(0.5) == k["fallback_shininess"] == 1025.0
+    import ctypes as C
+    v = (C.c_float * 3)(*k["fallback_light_dir"])
+    one = (C.c_float * 3)(1.0, 1.0, 1.0)
+    alb = (C.c_float * 3)(0.7, 0.7, 0.7)
+    out = (C.c_float * 3)()
+    L.oracle_blinn_phong(v, v, v, one, alb, C.c_float(1025.0), out)   # N = L = V
+    assert out[0] + k["ambient_per_channel"] == pytest.approx(k["aligned_NLV_color"], abs=2e-5)
+
+
+def test_k3_fallback_model_pixel(oracle, scenes):
+    """A quad facing the fallback light direction, viewed along it: colour = 0.021 + 0.7 + 1 = 1.721."""
+    k = KATS["K3_shader_constants"]
+    n = np.array([1.0, 1.0, 1.0]) / math.sqrt(3.0)
+    u = np.cross(n, [0.0, 1.0, 0.0]); u /= np.linalg.norm(u)
+    v = np.cross(n, u)
+    pos = np.array([-u - v, u - v, u + v, -u + v]) * 0.5
+    verts = np.zeros((4, 12), dtype=np.float32)
+    verts[:, 0:3] = pos; verts[:, 3:6] = n; verts[:, 8:12] = [1, 0, 0, 1]
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    eye = n * 300.0   # far away: V ~ n everywhere
+    view = scenes.look_at_rh(eye, (0, 0, 0), (0, 1, 0))
+    proj = scenes.projection_vulkan(math.radians(1.0), 1.0, 0.1, 1000.0)
+    d = scenes.DrawSpec(vertices=verts, stride=48, count=6, indices=idx, program=scenes.PROGRAM_MODEL,
+                        cull_mode=scenes.CULL_NONE, camera=scenes.camera_ubo(view, proj, eye),
+                        object=scenes.object_ubo(np.eye(4, dtype=np.float32)))
+    r = oracle.render(scenes.Scene("k3", 64, 64, [d]))
+    c = r["rgba"][32, 32]
+    assert c[:3] == pytest.approx([k["aligned_NLV_color"]] * 3, abs=2e-3) and c[3] == 1.0
+    assert oracle.lib().oracle_srgb8(float(c[0])) == 255      # saturates in the sRGB8 target
+
+
+def test_k4_default_camera_matrices(oracle):
+    """crates/scene/src/camera.rs:43-56,110-142 + the reference's tests camera.rs:552-569."""
+    k = KATS["K4_matrices"]
+    p = k["perspective"]
+    P = oracle.mat_fn("oracle_camera_projection_perspective", math.radians(p["fovy_deg"]), p["aspect"], p["near"], p["far"])
+    # column-major storage: P[col][row]
+    assert P[0, 0] == pytest.approx(p["w"], rel=1e-6) and P[1, 1] == pytest.approx(p["m11_after_flip"], rel=1e-6)
+    assert P[1, 1] < 0                                           # camera.rs:563-569
+    assert P[2, 2] == pytest.approx(p["r"], rel=1e-6) and P[2, 3] == -1.0 and P[3, 2] == pytest.approx(p["m32"], rel=1e-6)
+    V = oracle.mat_fn("oracle_camera_view_matrix", k["default_eye"], [0.0, 0.0, 0.0, 1.0])
+    origin = V.T @ np.array([0, 0, 0, 1], dtype=np.float32)
+    assert origin[:3] == pytest.approx(k["view_times_origin"], abs=1e-5)   # camera.rs:552-560
+
+
+def test_k4_ubo_and_transform_behaviour(oracle, scenes):
+    """ubo.rs:436-448 (view_projection == projection*view), :479-523 (normal matrix), transform.rs:231-267."""
+    view = scenes.look_at_rh((0, 2, 5), (0, 0, 0), (0, 1, 0))
+    proj = scenes.perspective_rh(math.radians(45.0), 16 / 9, 0.1, 100.0)
+    vp = oracle.mat_fn("oracle_glam_mat4_mul", proj, view)
+    assert np.allclose(vp, scenes.mat_mul(proj, view), atol=1e-6)
+    # normal matrix = inverse transpose; zero scale -> identity
+    m = scenes.trs((2.0, 3.0, 4.0), scenes.quat_axis_angle((0, 1, 0), 0.7), (1.0, 2.0, 3.0))
+    nm = oracle.mat_fn("oracle_normal_matrix", m)
+    want = np.linalg.inv(m.T.astype(np.float64)).T.T
+    assert np.allclose(nm, want, atol=1e-5)
+    z = scenes.trs((0.0, 1.0, 1.0), (0, 0, 0, 1), (0, 0, 0))
+    assert np.array_equal(oracle.mat_fn("oracle_normal_matrix", z), np.eye(4, dtype=np.float32))
+    # TRS composition: translation after rotation after scale
+    t = oracle.mat_fn("oracle_glam_from_scale_rotation_translation", [2.0, 2.0, 2.0], [0.0, 0.0, 0.0, 1.0], [1.0, 2.0, 3.0])
+    assert np.allclose(t.T @ np.array([1, 1, 1, 1], dtype=np.float32), [3, 4, 5, 1])
+    assert np.allclose(t, scenes.trs((2, 2, 2), (0, 0, 0, 1), (1, 2, 3)))
+
+
+def test_k6_layouts(scenes):
+    """vertex.rs:177-319 and ubo.rs:421-596 size/offset assertions, as seen by the byte builders."""
+    k = KATS["K6_layouts"]
+    s = scenes.hello_triangle()
+    assert s.draws[0].stride == k["TriangleVertex"]["size"] and s.draws[0].vertex_bytes().size == 3 * 24
+    v = scenes._pack_vertex48(np.zeros((1, 3)), np.ones((1, 3)), np.full((1, 2), 2.0), np.full((1, 4), 3.0)).view(np.uint8).reshape(-1)
+    f = v.view(np.float32)
+    assert v.size == k["Vertex"]["size"]
+    assert f[k["Vertex"]["normal"] // 4] == 1.0 and f[k["Vertex"]["tex_coord"] // 4] == 2.0 and f[k["Vertex"]["tangent"] // 4] == 3.0
+    view, proj, cam = scenes.default_camera(1920, 1080)
+    assert len(cam) == k["CameraUbo"]["size"]
+    assert np.frombuffer(cam, dtype=np.float32)[k["CameraUbo"]["camera_position"] // 4 + 2] == 5.0
+    assert len(scenes.object_ubo(np.eye(4, dtype=np.float32))) == k["ObjectUbo"]["size"]
+    assert len(scenes.light_ubo()) == k["LightUBO_hlsl"]["size"] and len(scenes.material_ubo()) == k["MaterialData_hlsl"]["size"]
+    assert len(scenes.point_light((0, 0, 0), 1, (1, 1, 1), 1)) == k["PointLight"]["size"]
+    assert len(scenes.spot_light((0, 0, 0), 1, (0, 0, 1), 0, (1, 1, 1), 1)) == k["SpotLight_hlsl"]["size"]
+
+
+def test_oracle_edge_cases(oracle, scenes):
+    """Domain edge cases: shared edges are covered exactly once, depth ties keep the earlier primitive,
+    back faces are culled, scissor clips, off-screen / degenerate input yields the clear colour."""
+    fan = scenes.shared_edge_fan()
+    r = oracle.render(fan)
+    # every covered pixel is hit by exactly one fan triangle: brute-force count with the oracle itself,
+    # one triangle at a time, must sum to the union
+    total = np.zeros((fan.height, fan.width), dtype=np.int32)
+    d = fan.draws[0]
+    for t in range(d.num_triangles):
+        one = scenes.DrawSpec(vertices=d.vertices[3 * t:3 * t + 3], stride=24, count=3, cull_mode=scenes.CULL_NONE,
+                              depth_test=False, depth_write=False)
+        total += (oracle.render(scenes.Scene("one", fan.width, fan.height, [one]))["prim"] != 0xFFFFFFFF)
+    assert total.max() == 1 and np.array_equal(total == 1, r["prim"] != 0xFFFFFFFF)
+    tie = oracle.render(scenes.depth_tie_case())
+    both = tie["prim"][32, 48]
+    assert both == 0          # triangles 0 and 1 overlap at equal depth: LESS keeps primitive 0
+    cs = oracle.render(scenes.cull_scissor_case())
+    assert set(np.unique(cs["prim"])) <= {0, 0xFFFFFFFF} or set(np.unique(cs["prim"])) <= {1, 0xFFFFFFFF}
+    ys, xs = np.where(cs["prim"] != 0xFFFFFFFF)
+    assert xs.min() >= 16 and xs.max() < 16 + 90 and ys.min() >= 8 and ys.max() < 8 + 60
+    empty = scenes.Scene("empty", 33, 17, [], clear_color=(0.25, 0.5, 0.75, 1.0))
+    e = oracle.render(empty)
+    assert (e["prim"] == 0xFFFFFFFF).all() and np.allclose(e["rgba"], [0.25, 0.5, 0.75, 1.0])
+
+
+def test_oracle_threads_and_bands_agree(oracle, scenes):
+    s = scenes.random_triangles(500, 320, 200, seed=9)
+    a = oracle.render(s, nthreads=1)
+    b = oracle.render(s, nthreads=5)
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["rgba"], b["rgba"]) and np.array_equal(a["bgra8"], b["bgra8"])
+    band = oracle.render(s, rows=(64, 128))
+    assert np.array_equal(band["prim"][64:128], a["prim"][64:128]) and (band["prim"][:64] == 0xFFFFFFFF).all()
+
+
+def test_near_clip_is_watertight(oracle, scenes):
+    """The ground quad crosses the near plane and w = 0: clipping must not leave cracks along the shared diagonal."""
+    r = oracle.render(scenes.near_clip_case())
+    cov = r["prim"] != 0xFFFFFFFF
+    assert cov.sum() > 1000 and not np.isnan(r["rgba"]).any()
+    # below the horizon every pixel of the bottom rows is ground
+    assert cov[-1].all() and cov[-20].all()
