@@ -1,0 +1,120 @@
+// test_host.cpp -- tests of the C++ host mirror (mirhi.hpp).  Without arguments: CPU-only checks that restate
+// the reference's own unit tests (camera.rs:551-569, transform.rs:211-453, ubo.rs:421-596, vertex.rs:177-319,
+// pipeline.rs:1177-1254, rendering.rs:1027-1073).  With --gpu: Renderer::render_frame / FrameManager on a MI355X.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "mirhi.hpp"
+
+using namespace mirhi;
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+static bool near(float a, float b, float eps = 1e-5f) { return std::fabs(a - b) <= eps; }
+static bool near3(Vec3 a, Vec3 b, float eps = 1e-5f) { return near(a.x, b.x, eps) && near(a.y, b.y, eps) && near(a.z, b.z, eps); }
+
+static void cpu_tests() {
+    // vertex.rs:177-319
+    CHECK(sizeof(TriangleVertex) == 24 && offsetof(TriangleVertex, color) == 12);
+    CHECK(sizeof(Vertex) == 48 && offsetof(Vertex, normal) == 12 && offsetof(Vertex, tex_coord) == 24 && offsetof(Vertex, tangent) == 32);
+    CHECK(Vertex::binding_description().stride == 48 && TriangleVertex::attribute_descriptions()[1].offset == 12);
+    CHECK(Vertex::attribute_descriptions()[3].offset == 32 && Vertex::attribute_descriptions()[2].location == 2);
+    // camera.rs:551-569
+    Camera cam;
+    CHECK(near3(cam.view_matrix().transform_point3(Vec3::ZERO()), {0.0f, 0.0f, -5.0f}));
+    CHECK(cam.projection_matrix().at(1, 1) < 0.0f);
+    CHECK(near(cam.projection_matrix().at(0, 0), 1.35799513f, 1e-6f) && near(cam.projection_matrix().at(1, 1), -2.41421356f, 1e-6f));
+    CHECK(near(cam.projection_matrix().at(2, 2), -1.00010001f, 1e-6f) && near(cam.projection_matrix().at(2, 3), -0.100010001f, 1e-7f));
+    CHECK(cam.view_projection_matrix() == cam.projection_matrix() * cam.view_matrix());
+    cam.set_rotation(0.0f, 3.14159265f * 0.5f);                 // yaw 90 deg: forward = -X
+    CHECK(near3(cam.forward(), {-1.0f, 0.0f, 0.0f}, 1e-6f));
+    cam.set_rotation(10.0f, 0.0f);                              // pitch clamps to 89 deg
+    CHECK(cam.forward().y < 0.99999f && cam.forward().y > 0.999f);
+    // ubo.rs:421-523
+    CHECK(sizeof(CameraUbo) == 208 && offsetof(CameraUbo, projection) == 64 && offsetof(CameraUbo, view_projection) == 128 && offsetof(CameraUbo, camera_position) == 192);
+    CHECK(sizeof(ObjectUbo) == 128 && offsetof(ObjectUbo, normal_matrix) == 64);
+    const Mat4 view = Mat4::look_at_rh({0, 2, 5}, {0, 0, 0}, {0, 1, 0});
+    const Mat4 proj = Mat4::perspective_rh(45.0f * 3.14159265f / 180.0f, 16.0f / 9.0f, 0.1f, 100.0f);
+    CameraUbo cu(view, proj, {0, 2, 5});
+    CHECK(cu.view_projection == proj * view);
+    const Mat4 model = Mat4::from_scale_rotation_translation({2, 3, 4}, Quat::IDENTITY(), {1, 2, 3});
+    ObjectUbo ou(model);
+    CHECK(ou.normal_matrix == model.inverse().transpose());
+    CHECK(near(ou.normal_matrix.at(0, 0), 0.5f) && near(ou.normal_matrix.at(1, 1), 1.0f / 3.0f) && near(ou.normal_matrix.at(2, 2), 0.25f));
+    CHECK(ObjectUbo(Mat4::from_scale_rotation_translation({0, 1, 1}, Quat::IDENTITY(), {})).normal_matrix == Mat4::IDENTITY());
+    CHECK(near(DirectionalLightUbo({0, -2, 0}, {1, 1, 1}, 1).direction.y, -1.0f) && DirectionalLightUbo({0, 0, 0}, {1, 1, 1}, 1).direction.length() == 0.0f);
+    // transform.rs:129-146,231-267,315-442
+    Transform parent; parent.with_position({10, 0, 0});
+    Transform child; child.with_position({0, 5, 0}).with_parent(parent);
+    CHECK(near3(child.world_matrix().transform_point3(Vec3::ZERO()), {10, 5, 0}, 1e-3f));
+    CHECK(child.has_parent());
+    child.clear_parent();
+    CHECK(!child.has_parent() && child.world_matrix() == child.local_matrix());
+    Transform t; t.with_scale({2, 2, 2}).with_rotation(Quat::from_axis_angle(Vec3::Y(), 3.14159265f * 0.5f)).with_position({1, 0, 0});
+    CHECK(near3(t.world_matrix().transform_point3({1, 0, 0}), {1, 0, -2}, 1e-5f));
+    Transform zero; zero.with_scale({0, 1, 1});
+    CHECK(zero.normal_matrix() == Mat4::IDENTITY());
+    // lights: Rust layout -> HLSL layout
+    SpotLight sl;
+    HlslSpotLight hs = to_hlsl(sl);
+    CHECK(hs.inner_cone_cos == 0.9f && hs.outer_cone_cos == 0.8f && hs.intensity == 1.0f);
+    // pipeline.rs:1177-1189,1230-1254 defaults; rendering.rs:1027-1073
+    GraphicsPipelineBuilder b;
+    CHECK(b.desc().topology == MIRHI_TOPOLOGY_TRIANGLE_LIST && b.desc().cull_mode == MIRHI_CULL_BACK && b.desc().front_face == MIRHI_FRONT_FACE_COUNTER_CLOCKWISE);
+    CHECK(b.desc().depth_test_enable == 1 && b.desc().depth_write_enable == 1 && b.desc().depth_compare_op == MIRHI_COMPARE_LESS);
+    mirhi_rendering_info ri; mirhi_rendering_info_default(&ri);
+    CHECK(ri.color_load_op == MIRHI_LOAD_OP_CLEAR && ri.color_store_op == MIRHI_STORE_OP_STORE && ri.clear_color[3] == 1.0f && ri.clear_color[0] == 0.0f);
+    CHECK(ri.depth_load_op == MIRHI_LOAD_OP_CLEAR && ri.depth_store_op == MIRHI_STORE_OP_DONT_CARE && ri.clear_depth == 1.0f);
+    CHECK(MAX_FRAMES_IN_FLIGHT == 2 && DEFAULT_DEPTH_FORMAT == Format::D32_SFLOAT);
+    // model.rs defaults through the interleave helper
+    Mesh mesh; mesh.positions = {{0, 0, 0}, {1, 0, 0}};
+    auto vs = mesh.interleave();
+    CHECK(vs.size() == 2 && vs[1].normal.y == 1.0f && vs[0].tangent.x == 1.0f && vs[0].tangent.w == 1.0f && vs[1].tex_coord.x == 0.0f);
+    // no GPU -> NoSuitableGpu, never a fallback
+    int32_t n = 0; mirhi_device_count(&n);
+    if (n == 0) {
+        bool threw = false;
+        try { Device::create(0); } catch (const RhiError& e) { threw = e.kind == RhiErrorKind::NoSuitableGpu; }
+        CHECK(threw);
+    }
+}
+
+static void gpu_tests() {
+    Renderer r(256, 256);
+    for (int i = 0; i < 5; i++) r.render_frame();             // > MAX_FRAMES_IN_FLIGHT: fences are waited and reused
+    r.wait_idle();
+    std::vector<uint8_t> px(256 * 256 * 4);
+    r.last_image().read(px.data());
+    int covered = 0;
+    for (int i = 0; i < 256 * 256; i++) if (!(px[4 * i] == 108 && px[4 * i + 1] == 89 && px[4 * i + 2] == 89)) covered++;
+    CHECK(covered == 8192);                                     // K2
+    CHECK(px[0] == 108 && px[1] == 89 && px[2] == 89 && px[3] == 255);   // BGRA sRGB8 of (0.1, 0.1, 0.15, 1)
+    const uint8_t* c = &px[4 * (149 * 256 + 128)];
+    CHECK(std::abs((int)c[0] - 156) <= 2 && std::abs((int)c[1] - 156) <= 2 && std::abs((int)c[2] - 156) <= 2);
+    r.resize(320, 200);
+    r.render_frame();
+    r.wait_idle();
+    CHECK(r.width() == 320 && r.last_image().height() == 200);
+    // reference error behaviour through the C++ types
+    bool threw = false;
+    try { Buffer bad(r.device(), BufferUsage::Vertex, 0); } catch (const RhiError& e) { threw = e.kind == RhiErrorKind::InvalidHandle && std::strstr(e.what(), "Buffer size must be greater than 0"); }
+    CHECK(threw);
+    threw = false;
+    try { GraphicsPipelineBuilder().build(r.device()); } catch (const RhiError& e) { threw = e.kind == RhiErrorKind::PipelineError && std::strstr(e.what(), "Vertex shader is required"); }
+    CHECK(threw);
+    Fence f(r.device(), true);
+    CHECK(f.is_signaled());
+    f.reset();
+    CHECK(!f.is_signaled());
+}
+
+int main(int argc, char** argv) {
+    cpu_tests();
+    if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) {
+        try { gpu_tests(); } catch (const RhiError& e) { std::printf("FAIL: RhiError %s\n", e.what()); failures++; }
+    }
+    std::printf(failures ? "host tests: %d FAILED\n" : "host tests: ok\n", failures);
+    return failures ? 1 : 0;
+}

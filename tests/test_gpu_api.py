@@ -1,0 +1,290 @@
+"""GPU tests of the drop-in boundary: same names, argument meaning and error behaviour as crates/rhi and the
+crates/renderer draw-submit loop, exercised through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_buffer_semantics(mirhi, device):
+    """crates/rhi/src/buffer.rs:149-293,345-417 (+ its tests :442-553)."""
+    with pytest.raises(mirhi.RhiError) as e:
+        mirhi.Buffer(device, mirhi.BufferUsage.Vertex, 0)
+    assert e.value.variant == "InvalidHandle" and "Buffer size must be greater than 0" in e.value.message
+    b = mirhi.Buffer(device, mirhi.BufferUsage.Vertex, 64)
+    assert b.size() == 64 and b.usage() == mirhi.BufferUsage.Vertex
+    b.write_data(0, b"")                                           # empty write is Ok (buffer.rs:248-250)
+    b.write_data(16, np.arange(12, dtype=np.float32))
+    with pytest.raises(mirhi.RhiError) as e:
+        b.write_data(32, np.zeros(9, dtype=np.float32))
+    assert "Write exceeds buffer size: offset 32 + data 36 > buffer 64" in e.value.message
+    assert np.array_equal(b.read(16, 48).view(np.float32), np.arange(12, dtype=np.float32))
+    b.destroy()
+    s = mirhi.Buffer(device, mirhi.BufferUsage.Storage, 32)        # GpuOnly memory: not mapped (buffer.rs:86-100)
+    with pytest.raises(mirhi.RhiError) as e:
+        s.upload(np.zeros(4, dtype=np.uint32))
+    assert "Buffer memory is not mapped" in e.value.message
+    s.upload_via_staging(np.arange(8, dtype=np.uint32))
+    assert np.array_equal(s.read(0, 32).view(np.uint32), np.arange(8, dtype=np.uint32))
+    s.destroy()
+    v = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Index, np.arange(6, dtype=np.uint16))
+    assert v.size() == 12
+    v.destroy()
+
+
+def _tri_builder(mirhi):
+    return (mirhi.GraphicsPipelineBuilder().vertex_shader(mirhi.Program.TRIANGLE).fragment_shader(mirhi.Program.TRIANGLE)
+            .vertex_binding(24).vertex_attributes((0, 12)).color_attachment_format(mirhi.Format.R32G32B32A32_SFLOAT))
+
+
+def test_pipeline_build_validation_order_and_text(mirhi, device):
+    """GraphicsPipelineBuilder::build (pipeline.rs:918-952): same checks, same order, same messages."""
+    B = mirhi.GraphicsPipelineBuilder
+
+    def err(builder):
+        with pytest.raises(mirhi.RhiError) as e:
+            builder.build(device)
+        assert e.value.variant in ("PipelineError", "ShaderError")
+        return e.value.message
+
+    assert "Vertex shader is required" in err(B())
+    assert "Fragment shader is required" in err(B().vertex_shader(mirhi.Program.TRIANGLE))
+    assert "At least one color attachment format is required" in err(
+        B().vertex_shader(mirhi.Program.TRIANGLE).fragment_shader(mirhi.Program.TRIANGLE))
+    assert "Depth test or write is enabled but no depth attachment format is specified" in err(_tri_builder(mirhi))
+    ok = _tri_builder(mirhi).depth_test_enable(False).depth_write_enable(False).cull_mode(mirhi.CullMode.NONE).build(device)
+    ok.destroy()
+    ok = _tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).build(device)
+    ok.destroy()
+    b = _tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT)
+    b.desc.blend_attachment_count = 2
+    assert "Blend attachment count (2) must match color attachment count (1)" in err(b)
+    # not implemented by the compute rasterizer: loud, never silently different
+    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).blend_enable(True))
+    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).topology(mirhi.PrimitiveTopology.TriangleStrip))
+    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).polygon_mode(mirhi.PolygonMode.Line))
+    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.Equal))
+    mixed = (B().vertex_shader(mirhi.Program.MODEL).fragment_shader(mirhi.Program.TRIANGLE).vertex_binding(48)
+             .vertex_attributes((0, 12, 24, 32)).color_attachment_format(mirhi.Format.R32G32B32A32_SFLOAT)
+             .depth_attachment_format(mirhi.Format.D32_SFLOAT))
+    assert "does not produce the inputs" in err(mixed)
+
+
+def test_fence_semantics(mirhi, device, scenes):
+    """Fence::new(signaled) / wait / reset / is_signaled (sync.rs:168-298)."""
+    f = mirhi.Fence(device, signaled=True)
+    assert f.is_signaled()
+    f.wait(0)
+    f.reset()
+    assert not f.is_signaled()
+    with pytest.raises(mirhi.RhiError) as e:
+        f.wait(1_000_000)                       # nothing submitted: times out like vkWaitForFences
+    assert e.value.code == mirhi.TIMEOUT and "TIMEOUT" in e.value.message
+    res = mirhi.SceneResources(device, scenes.hello_triangle(64, 64))
+    res.render(f)
+    f.wait()                                    # u64::MAX
+    assert f.is_signaled()
+    f.reset()
+    assert not f.is_signaled()
+    res.destroy()
+    f.destroy()
+
+
+def test_frames_in_flight_loop(mirhi, device, scenes):
+    """Renderer::render_frame ordering (renderer.rs:367-449): wait fence -> reset -> record -> submit, 2 frames in flight."""
+    scene = scenes.random_triangles(500, 320, 200, seed=3)
+    frames = [mirhi.SceneResources(device, scene, want_prim=True) for _ in range(mirhi.MAX_FRAMES_IN_FLIGHT)]
+    fences = [mirhi.Fence(device, signaled=True) for _ in frames]
+    cur = 0
+    for _ in range(7):
+        fences[cur].wait()
+        fences[cur].reset()
+        frames[cur].record()                    # reset + begin + commands + end each frame, as the reference does
+        frames[cur].render(fences[cur])
+        cur = (cur + 1) % mirhi.MAX_FRAMES_IN_FLIGHT
+    for f in fences:
+        f.wait()
+    a, b = frames[0].read(), frames[1].read()
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["color"], b["color"])
+    for r in frames:
+        r.destroy()
+    for f in fences:
+        f.destroy()
+
+
+def test_command_buffer_state_errors(mirhi, device):
+    cmd = mirhi.CommandBuffer(device)
+    with pytest.raises(mirhi.RhiError):
+        cmd.end()                               # not recording
+    with pytest.raises(mirhi.RhiError):
+        cmd.draw(3)
+    img = mirhi.Image(device, 32, 32, mirhi.Format.R32G32B32A32_SFLOAT)
+    cmd.begin()
+    with pytest.raises(mirhi.RhiError) as e:
+        cmd.draw(3)
+    assert "outside a rendering scope" in e.value.message
+    cmd.begin_rendering(img)
+    with pytest.raises(mirhi.RhiError) as e:
+        cmd.draw(3)
+    assert "no pipeline bound" in e.value.message
+    with pytest.raises(mirhi.RhiError):
+        cmd.end()                               # still inside the rendering scope
+    cmd.end_rendering()
+    cmd.end()
+    fresh = mirhi.CommandBuffer(device)
+    with pytest.raises(mirhi.RhiError):
+        device.submit([fresh])                  # never recorded
+    fresh.destroy()
+    device.submit([cmd])                        # an empty scope just clears
+    device.wait_idle()
+    assert np.allclose(img.read(), [0.0, 0.0, 0.0, 1.0])  # ColorAttachment default clear (rendering.rs:108-112)
+    with pytest.raises(mirhi.RhiError) as e:
+        mirhi.Image(device, 0, 16, mirhi.Format.D32_SFLOAT)  # DepthBuffer::new rejects 0 (depth_buffer.rs:118-127)
+    assert "must be greater than 0" in e.value.message
+    cmd.destroy()
+    img.destroy()
+
+
+def test_draw_bounds_are_checked(mirhi, device):
+    img = mirhi.Image(device, 32, 32, mirhi.Format.R32G32B32A32_SFLOAT)
+    pipe = _tri_builder(mirhi).depth_test_enable(False).depth_write_enable(False).build(device)
+    vb = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, np.zeros((3, 6), dtype=np.float32))
+    ib = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Index, np.arange(3, dtype=np.uint32))
+    cmd = mirhi.CommandBuffer(device)
+    cmd.begin()
+    cmd.begin_rendering(img)
+    cmd.bind_pipeline(pipe)
+    cmd.bind_vertex_buffers(0, [vb], [0])
+    with pytest.raises(mirhi.RhiError) as e:
+        cmd.draw(3)
+    assert "viewport and scissor" in e.value.message            # dynamic state (pipeline.rs:697)
+    cmd.set_viewport(0, 0, 32, 32)
+    cmd.set_scissor(0, 0, 32, 32)
+    with pytest.raises(mirhi.RhiError) as e:
+        cmd.draw(6)
+    assert "beyond the bound vertex buffer" in e.value.message
+    cmd.bind_index_buffer(ib, 0, mirhi.IndexType.UINT32)
+    with pytest.raises(mirhi.RhiError) as e:
+        cmd.draw_indexed(6)
+    assert "beyond the bound index buffer" in e.value.message
+    cmd.draw(3)
+    cmd.draw_indexed(3)
+    cmd.end_rendering()
+    cmd.end()
+    device.submit([cmd])
+    device.wait_idle()
+    for o in (cmd, vb, ib, pipe, img):
+        o.destroy()
+
+
+def test_device_refuses_destroy_with_live_children(mirhi):
+    dev = mirhi.Device(0)
+    b = mirhi.Buffer(dev, mirhi.BufferUsage.Uniform, 16)
+    with pytest.raises(mirhi.RhiError) as e:
+        dev.destroy()
+    assert "live child" in e.value.message
+    b.destroy()
+    dev.destroy()
+
+
+def test_tile_row_split_bands_assemble(mirhi, oracle, scenes):
+    """each rank renders its band of tile rows; bands tile the frame exactly."""
+    from renderer_rs_amd import multigpu
+    scene = scenes.random_triangles(3000, 640, 360, seed=12, rmin=3, rmax=60)
+    ref = oracle.render(scene, want_bgra8=False)
+    world = 4
+    out_prim = np.full((scene.height, scene.width), 0xFFFFFFFF, dtype=np.uint32)
+    out_col = np.zeros((scene.height, scene.width, 4), dtype=np.float32)
+    for rank in range(world):
+        dev = mirhi.Device(0)
+        dev.set_tile_split(rank, world)
+        r0, r1 = dev.band_rows(scene.height)
+        assert (r0, r1) == multigpu.band_rows(scene.height, rank, world)
+        res = mirhi.SceneResources(dev, scene, want_prim=True)
+        res.color.upload(np.full((scene.height, scene.width, 4), -7.0, dtype=np.float32))   # sentinel
+        res.render()
+        got = res.read()
+        assert (got["color"][:r0] == -7.0).all() and (got["color"][r1:] == -7.0).all()       # other bands untouched
+        out_prim[r0:r1] = got["prim"][r0:r1]
+        out_col[r0:r1] = got["color"][r0:r1]
+        res.destroy()
+        dev.destroy()
+    assert np.array_equal(out_prim, ref["prim"])
+    assert np.abs(out_col[..., :3] - ref["rgba"][..., :3]).max() < 1e-4
+
+
+def test_two_scopes_load_color_and_depth(mirhi, oracle, device, scenes):
+    """LOAD / STORE ops (rendering.rs:200-209,455-470): drawing B in a second scope over A's colour + depth equals
+    drawing A and B in one scope."""
+    W, H = 256, 160
+    a = scenes.random_triangles(120, W, H, seed=31, rmin=5, rmax=50).draws[0]
+    b = scenes.random_triangles(120, W, H, seed=32, rmin=5, rmax=50).draws[0]
+    both = scenes.Scene("ab", W, H, [a, b], clear_color=(0.2, 0.1, 0.3, 1.0))
+    ref = oracle.render(both, want_bgra8=False)
+    color = mirhi.Image(device, W, H, mirhi.Format.R32G32B32A32_SFLOAT)
+    depth = mirhi.Image(device, W, H, mirhi.Format.D32_SFLOAT)
+    pipe = (_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).cull_mode(mirhi.CullMode.NONE).build(device))
+    vba = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, a.vertices)
+    vbb = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, b.vertices)
+    cmd = mirhi.CommandBuffer(device)
+    cmd.begin()
+    for i, (vb, d) in enumerate(((vba, a), (vbb, b))):
+        cmd.begin_rendering(color, clear_color=both.clear_color, color_load_op=mirhi.LoadOp.CLEAR if i == 0 else mirhi.LoadOp.LOAD,
+                            depth=depth, depth_load_op=mirhi.LoadOp.CLEAR if i == 0 else mirhi.LoadOp.LOAD,
+                            depth_store_op=mirhi.StoreOp.STORE)
+        cmd.set_viewport(0, 0, W, H)
+        cmd.set_scissor(0, 0, W, H)
+        cmd.bind_pipeline(pipe)
+        cmd.bind_vertex_buffers(0, [vb], [0])
+        cmd.draw(d.count)
+        cmd.end_rendering()
+    cmd.end()
+    device.submit([cmd])
+    device.wait_idle()
+    got_c, got_d = color.read(), depth.read()
+    assert np.abs(got_c[..., :3] - ref["rgba"][..., :3]).max() < 1e-4
+    assert np.array_equal(got_d.view(np.uint32), ref["depth"].view(np.uint32))
+    for o in (cmd, vba, vbb, pipe, color, depth):
+        o.destroy()
+
+
+def test_uniform_update_between_submits(mirhi, oracle, device, scenes):
+    """Uniform buffers are host-coherent in the reference (buffer.rs:86-100): write_data between submits is seen."""
+    scene = scenes.displaced_sphere(16, 11, 160, 120, seed=4, program=scenes.PROGRAM_MODEL)
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render()
+    first = res.read()
+    model = scenes.trs((1.2, 0.8, 1.0), scenes.quat_axis_angle((0, 0, 1), 0.9), (0.3, -0.2, 0.0))
+    scene.draws[0].object = scenes.object_ubo(model)
+    res.draw_state[0]["object"].write_data(0, scene.draws[0].object)
+    res.render()
+    second = res.read()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert not np.array_equal(first["prim"], second["prim"])
+    assert np.array_equal(second["prim"], ref["prim"])
+    res.destroy()
+
+
+def test_big_list_and_bin_spill_paths(mirhi, oracle, device, scenes):
+    """Many triangles in one tile overflow its bin into the big list; the result is unchanged (idempotent resolve)."""
+    n = 3000
+    rng = np.random.default_rng(5)
+    c = np.tile(np.array([[-0.9, -0.9]]), (n, 1)) + rng.uniform(0, 0.02, (n, 2))
+    pts = np.zeros((n, 3, 6), dtype=np.float32)
+    for k, (dx, dy) in enumerate(((0, 0), (0.03, 0.0), (0.0, 0.04))):
+        pts[:, k, 0] = c[:, 0] + dx
+        pts[:, k, 1] = c[:, 1] + dy
+        pts[:, k, 2] = rng.uniform(0.1, 0.9, n)[:]
+    pts[:, :, 3:] = rng.uniform(0, 1, (n, 1, 3))
+    d = scenes.DrawSpec(vertices=pts.reshape(-1, 6), stride=24, count=3 * n, cull_mode=scenes.CULL_NONE)
+    scene = scenes.Scene("spill", 640, 480, [d])
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    f = mirhi.Fence(device)
+    res.render(f)
+    f.wait()
+    assert device.stats().last_big_list > 0          # the bin (capacity << 3000) spilled
+    got = res.read()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(got["prim"], ref["prim"])
+    res.destroy()
+    f.destroy()
