@@ -41,6 +41,11 @@ def parse_args():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--split", default="none", choices=["none", "rows"])
     ap.add_argument("--format", default="bgra8", choices=["bgra8", "rgba32f"])
+    ap.add_argument("--frames-in-flight", type=int, default=4,
+                    help="independent frames (own command buffer + target) overlapped on the GPU; the reference keeps 2 "
+                         "(MAX_FRAMES_IN_FLIGHT) + 1 swapchain image")
+    ap.add_argument("--profile-pass-only", action="store_true",
+                    help="only the isolated per-kernel timing pass (one frame at a time): the command profiled with rocprofv3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -59,7 +64,7 @@ def cpu_baseline(scene, seconds: float):
         ob.render(scene, nthreads=cores, want_bgra8=True)
         frames += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or frames >= 200:
+        if dt >= seconds or frames >= 2000:
             break
     return {"value": round(scene.num_triangles * frames / dt / 1e6, 4), "unit": "Mtris/s", "cores": cores, "kind": "port",
             "sample": f"{frames} whole frames of the same workload in {dt:.1f} s (oracle/mirhi_oracle.c, {cores} row-band threads)"}
@@ -97,6 +102,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     dev = m.Device(local_rank, stream=stream)
+    nfif = 1 if split else max(1, min(4, args.frames_in_flight))
+    dev.set_queue_lanes(nfif)
     if split:
         dev.set_tile_split(rank, world)
 
@@ -109,34 +116,49 @@ def main():
         return m.Buffer.wrap(device, usage, t.data_ptr(), t.numel())
 
     rows = multigpu.padded_rows(scene.height, world) if split else scene.height
-    nchan = 4 if bpp == 4 else 4
-    frame = torch.zeros((rows, scene.width, nchan), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
-    target = m.Image(dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
-    res = m.SceneResources(dev, scene, fmt, color_image=target, wrap_buffers=wrap)
+    frames, slots = [], []
+    shared = {}
+
+    def wrap_shared(device, usage, arr):     # geometry / uniforms are uploaded once and shared by all frames in flight
+        key = (usage, arr.ctypes.data, arr.size)
+        if key not in shared:
+            shared[key] = wrap(device, usage, arr)
+        return shared[key]
+
+    for _ in range(nfif):                    # one colour target + command buffer per frame in flight (swapchain images)
+        frame = torch.zeros((rows, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
+        target = m.Image(dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
+        frames.append(frame)
+        slots.append(m.SceneResources(dev, scene, fmt, color_image=target, wrap_buffers=wrap_shared))
+    res = slots[0]
+    counter = [0]
 
     def step():
-        res.render()
+        i = counter[0] % nfif
+        counter[0] += 1
+        slots[i].render()
         if split:
-            multigpu.all_gather_bands(frame, rank, world)
+            multigpu.all_gather_bands(frames[i], rank, world)
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(0 if args.profile_pass_only else args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max(time.perf_counter() - t0, 1e-9)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # per-kernel device time: HIP events recorded on the submit stream around each kernel, K more steps
+    # per-kernel device time: HIP event pairs recorded on the submit stream around each kernel, K more steps with
+    # ONE frame in flight (frames that overlap on the GPU would stretch each other's kernel durations)
     dev.set_profiling(True)
     dev.reset_kernel_times()
-    for _ in range(args.steps):
-        res.render()
+    for i in range(args.steps):
+        slots[0].render()
     torch.cuda.synchronize()
     geo_ms, geo_n = dev.kernel_time(m.Kernel.GEOMETRY)
     ras_ms, ras_n = dev.kernel_time(m.Kernel.RASTER)
@@ -164,23 +186,26 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "triangles": tris, "width": scene.width, "height": scene.height,
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
                        "parallelism": (f"tile-row split x{world} + RCCL all-gather" if split else (f"afr{world}" if world > 1 else "single")),
-                       "frames_per_step": 1},
+                       "frames_per_step": 1, "frames_in_flight": nfif},
             "shaded_mpix_per_s": round(scene.width * scene.height * frames_total / dt / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": round(ras_us, 3),
                          "geometry_kernel_us": round(geo_us, 3),
-                         "how": "hipEvent pairs on the submit stream around every launch, K extra steps after the timed region"},
+                         "how": "hipEvent pairs on the submit stream around every launch; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
             "workspace_mb": round(stats.workspace_bytes / 1e6, 1), "big_list": stats.last_big_list,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.profile_pass_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)
             except Exception as e:  # the oracle is a reported baseline, never the measured path
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
-    res.destroy()
+    seen = set()
+    for sl in slots:                          # shared buffers are destroyed once
+        sl.objs = [o for o in sl.objs if not (id(o) in seen or seen.add(id(o)))]
+        sl.destroy()
     dev.destroy()
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,31 @@
+import os, sys, ctypes as C, numpy as np
+os.environ["MIRHI_LIB_NAME"] = "libmirhi_stamps.so"
+import __graft_entry__ as ge
+m = ge.load_package()
+L = C.CDLL(m.LIB_PATH)
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+make = {"tri1": lambda: m.scenes.random_triangles(1), "c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid}[wl]
+scene = make()
+dev = m.Device(0)
+res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
+for _ in range(20): res.render()
+dev.wait_idle()
+def grab(kernel_waves):
+    buf = np.zeros(16384 * 8, dtype=np.uint64)
+    L.mirhi_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
+    return buf.reshape(-1, 8)
+# the stamp buffer is shared by both kernels: raster runs last, so it holds raster stamps for wave ids < raster waves
+st = grab(0).astype(np.int64)
+nw = min(16384, ((scene.width + 31) // 32) * ((scene.height + 31) // 32) * 4)
+s = st[:nw]
+ok = s[:, 4] > 0
+s = s[ok]
+t0 = s[:, 0].min()
+def us(c): return c / 100.0   # s_memtime ticks: 100 MHz constant clock
+print(f"raster waves {len(s)}: kernel span {us(s[:,4].max() - t0):.2f} us (first start -> last end)")
+for name, a, b in (("prologue (counters)", 0, 1), ("bin list (fill+raster)", 1, 2), ("  of which fill of first chunk", 1, 5), ("big list", 2, 3), ("resolve", 3, 4), ("whole wave", 0, 4)):
+    d = s[:, b] - s[:, a]
+    d = d[(s[:, b] > 0) & (s[:, a] > 0)]
+    if len(d): print(f"  {name:32s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
+print(f"  wave start spread: p50 {us(np.median(s[:,0]-t0)):.2f} us, max {us((s[:,0]-t0).max()):.2f} us")
+res.destroy(); dev.destroy()

@@ -68,6 +68,11 @@ mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t out_len);
 /* screen-tile-row split: this device rasterizes only tile rows owned by `rank` of `world`
  * (contiguous bands); rank 0 / world 1 = whole frame.  Gathering the bands is the caller's collective. */
 mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint32_t world);
+/* frames in flight (crates/renderer/src/lib.rs:43 MAX_FRAMES_IN_FLIGHT): command buffers are assigned round-robin to
+ * `lanes` submit streams at creation, so independent frames (own command buffer, own target) overlap on the GPU the way
+ * the reference's per-frame command buffers do between their semaphores.  Default 1 = strict submission order.  Set before
+ * creating command buffers.  Work submitted on different lanes is unordered unless a fence is waited. */
+mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t lanes);
 /* first/last+1 pixel row of the band rendered by this device for a target of `height` rows */
 mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end);
 
@@ -216,7 +221,9 @@ mirhi_result mirhi_fence_destroy(mirhi_fence* fence);
 /* ---- measurement: per-kernel device time from HIP events on the submit stream ---------- */
 typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_COUNT = 2 } mirhi_kernel_id;
 mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);   /* brackets each kernel with hipEvents */
-/* accumulated since the last reset; waits for outstanding events */
+/* accumulated since the last reset; waits for outstanding events.  The duration of an empty event pair on the stream
+ * (calibrated when profiling is enabled, ~4.6 us on MI355X) is subtracted per launch, so the figure matches the
+ * kernel duration rocprofv3 --kernel-trace reports. */
 mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches);
 mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev);
 typedef struct {

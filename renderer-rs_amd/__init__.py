@@ -20,7 +20,7 @@ from . import build as _build
 from . import scenes  # noqa: F401  (re-export)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmirhi.so")
+LIB_PATH = os.path.join(HERE, os.environ.get("MIRHI_LIB_NAME", "libmirhi.so"))   # MIRHI_LIB_NAME: diagnostic builds only
 INCLUDE = os.path.join(os.path.dirname(HERE), "include", "mirhi.h")
 
 # ---- enums (include/mirhi.h) ------------------------------------------------------------------------
@@ -146,6 +146,7 @@ _SIGNATURES = {
     "mirhi_device_destroy": (C.c_int32, [C.c_void_p]),
     "mirhi_device_name": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32]),
     "mirhi_device_set_tile_split": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "mirhi_device_set_queue_lanes": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_band_rows": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mirhi_buffer_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mirhi_buffer_create_with_data": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -206,7 +207,7 @@ def lib():
     """Loads libmirhi.so (building it first if the sources are newer). Raises if unavailable."""
     global _lib
     if _lib is None:
-        if _build.needs_build():
+        if _build.needs_build() and LIB_PATH.endswith("libmirhi.so"):
             _build.build()
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built (python __graft_entry__.py)")
@@ -258,6 +259,9 @@ class Device:
 
     def set_tile_split(self, rank: int, world: int):
         check(lib().mirhi_device_set_tile_split(self.handle, rank, world))
+
+    def set_queue_lanes(self, lanes: int):
+        check(lib().mirhi_device_set_queue_lanes(self.handle, lanes))
 
     def band_rows(self, height: int):
         a, b = C.c_uint32(), C.c_uint32()

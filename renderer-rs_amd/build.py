@@ -31,25 +31,34 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, suffix: str = "") -> str:
+    if not force and out == LIB and not needs_build():
         return LIB
     objs = []
     for s in SOURCES:
-        obj = os.path.join(CSRC, s + ".o")
+        obj = os.path.join(CSRC, s + suffix + ".o")
         cmd = [hipcc(), *FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out
+
+
+def build_stamps(verbose: bool = False) -> str:
+    """Diagnostic build with per-wave s_memtime stamps (never the product library)."""
+    return build(force=True, verbose=verbose, extra_flags=["-DMIRHI_STAMPS"], out=os.path.join(HERE, "libmirhi_stamps.so"),
+                 suffix=".stamps")
 
 
 if __name__ == "__main__":
+    if "--stamps" in sys.argv:
+        print(build_stamps(verbose=True))
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True,
           extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())
     print(LIB)

@@ -78,6 +78,7 @@ struct PassParams {
     uint32_t init_zk, init_idk;       // state of an uncovered pixel when depth is cleared
     uint32_t clear_depth_bits;
     float    clear_color[4];
+    uint32_t clear_packed;            // clear colour in the target's B8G8R8A8_SRGB encoding (host-computed)
     uint32_t color_load;              // 1 = keep existing colour where nothing is drawn
     uint32_t color_format;            // mirhi_format
     void*    color;

@@ -25,14 +25,38 @@
 
 namespace mirhi {
 
+#ifdef MIRHI_STAMPS
+// Diagnostic build only (build.py --stamps -> libmirhi_stamps.so): per-wave s_memtime stamps at phase
+// boundaries, written to a buffer nothing else reads.  Never compiled into libmirhi.so.
+__device__ uint64_t g_stamps[16384 * 8];
+#define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
+    if (wv < 16384u) g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 
 __device__ __forceinline__ float ldf(const uint8_t* p, uint32_t off) { return *reinterpret_cast<const float*>(p + off); }
 __device__ __forceinline__ uint32_t ldu(const uint8_t* p, uint32_t off) { return *reinterpret_cast<const uint32_t*>(p + off); }
 
+// Draw descriptors and uniform blocks are read-only for the whole launch.  Reading them through the constant
+// address space lets the compiler use scalar loads (SGPRs, scalar cache) whenever the address is wave-uniform;
+// through a plain pointer it must assume the kernel's own stores may alias and falls back to vector loads.
+#define MIRHI_CONST __attribute__((address_space(4)))
+typedef const MIRHI_CONST DrawDesc* DrawPtr;
+typedef const MIRHI_CONST float* CFloatPtr;
+typedef const MIRHI_CONST uint8_t* CBytePtr;
+__device__ __forceinline__ DrawPtr const_draws(const DrawDesc* p) { return (DrawPtr)(uintptr_t)p; }
+__device__ __forceinline__ CFloatPtr cf(const float* p) { return (CFloatPtr)(uintptr_t)p; }
+__device__ __forceinline__ CBytePtr cb(const uint8_t* p) { return (CBytePtr)(uintptr_t)p; }
+__device__ __forceinline__ float ldcf(CBytePtr p, uint32_t off) { return *reinterpret_cast<const MIRHI_CONST float*>(p + off); }
+__device__ __forceinline__ uint32_t ldcu(CBytePtr p, uint32_t off) { return *reinterpret_cast<const MIRHI_CONST uint32_t*>(p + off); }
+typedef const MIRHI_CONST DrawDesc& DrawRef;
+
 // HLSL mul(M, v), M column-major (vertex/model.hlsl:44,48); accumulation order = oracle's.
-__device__ __forceinline__ f4 mat4_mul(const float* m, f4 v) {
+__device__ __forceinline__ f4 mat4_mul(CFloatPtr m, f4 v) {
     f4 r;
     r.x = ((m[0] * v.x + m[4] * v.y) + m[8] * v.z) + m[12] * v.w;
     r.y = ((m[1] * v.x + m[5] * v.y) + m[9] * v.z) + m[13] * v.w;
@@ -40,7 +64,7 @@ __device__ __forceinline__ f4 mat4_mul(const float* m, f4 v) {
     r.w = ((m[3] * v.x + m[7] * v.y) + m[11] * v.z) + m[15] * v.w;
     return r;
 }
-__device__ __forceinline__ f3 mat3_mul(const float* m, f3 v) {
+__device__ __forceinline__ f3 mat3_mul(CFloatPtr m, f3 v) {
     f3 r;
     r.x = (m[0] * v.x + m[4] * v.y) + m[8] * v.z;
     r.y = (m[1] * v.x + m[5] * v.y) + m[9] * v.z;
@@ -62,7 +86,7 @@ __device__ __forceinline__ float saturatef(float x) { return x > 0.0f ? (x < 1.0
 // ------------------------------------------------------------------------------------------------
 // a1/a2/a4: index fetch, vertex fetch, vertex-shader position
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fetch_index(const DrawDesc& D, uint32_t k) {
+__device__ __forceinline__ uint32_t fetch_index(DrawRef D, uint32_t k) {
     if (D.index_type == 0) return D.first + k;
     uint32_t idx;
     if (D.index_type == 2) idx = reinterpret_cast<const uint16_t*>(D.ib)[D.first + k];
@@ -70,16 +94,16 @@ __device__ __forceinline__ uint32_t fetch_index(const DrawDesc& D, uint32_t k) {
     return (uint32_t)((int32_t)idx + D.vertex_offset);
 }
 
-__device__ __forceinline__ f4 vs_position(const DrawDesc& D, uint32_t vidx, f3* world) {
+__device__ __forceinline__ f4 vs_position(DrawRef D, uint32_t vidx, f3* world) {
     const uint8_t* v = D.vb + (size_t)vidx * D.stride;
     f4 p = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};
     if (D.program == 0) {                                   // vertex/triangle.hlsl:19
         if (world) *world = {p.x, p.y, p.z};
         return p;
     }
-    f4 w = mat4_mul(D.object, p);                           // vertex/model.hlsl:44
+    f4 w = mat4_mul(cf(D.object), p);                       // vertex/model.hlsl:44
     if (world) *world = {w.x, w.y, w.z};
-    return mat4_mul(D.camera + 32, w);                      // :48 (viewProjection @128 B)
+    return mat4_mul(cf(D.camera) + 32, w);                  // :48 (viewProjection @128 B)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,7 +126,7 @@ __device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
 // ------------------------------------------------------------------------------------------------
 // a5: clip-space triangle (all w > 0) -> snapped, culled, oriented screen triangle + depth plane
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool setup_triangle(const PassParams& P, const DrawDesc& D, const f4 c[3], uint32_t prim,
+__device__ __forceinline__ bool setup_triangle(const PassParams& P, DrawRef D, const f4 c[3], uint32_t prim,
                                                ScreenTri& t) {
     float z[3];
 #pragma unroll
@@ -254,7 +278,7 @@ __device__ __forceinline__ uint32_t outcode_view(f4 c) {
 // the big list (the raster kernel builds its tile records), so this path needs no binning code.
 constexpr int CLIP_MAX_VERTS = 10;     // 3 + one per plane (near, far, 4 guard-band planes) = 9
 
-__device__ __forceinline__ void clip_and_emit(const PassParams& P, const DrawDesc& D, f4 (*poly)[CLIP_MAX_VERTS],
+__device__ __forceinline__ void clip_and_emit(const PassParams& P, DrawRef D, f4 (*poly)[CLIP_MAX_VERTS],
                                               f4 c0, f4 c1, f4 c2, uint32_t any, uint32_t prim) {
     f4* in = poly[0]; f4* tmp = poly[1];
     in[0] = c0; in[1] = c1; in[2] = c2;
@@ -288,7 +312,7 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
     uint32_t lo = 0, hi = P.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (P.draws[mid].prim_base <= prim) lo = mid; else hi = mid;
+        if (const_draws(P.draws)[mid].prim_base <= prim) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -297,13 +321,14 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
 // and pipeline-state word) is wave-uniform and lives in SGPRs
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
     __shared__ f4 poly[GEOM_THREADS][2][CLIP_MAX_VERTS];
+    STAMP(0);
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     uint32_t lo = 0, hi = P.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (P.draws[mid].slot_base <= slot0) lo = mid; else hi = mid;
+        if (const_draws(P.draws)[mid].slot_base <= slot0) lo = mid; else hi = mid;
     }
-    const DrawDesc& D = P.draws[lo];
+    DrawRef D = const_draws(P.draws)[lo];
     const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
     const uint32_t prim = D.prim_base + tri;
     bool valid = false;
@@ -319,8 +344,11 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             if (any == 0) valid = setup_triangle(P, D, c, prim, t);
         }
     }
+    STAMP(1);
     bin_triangle(P, valid, t);
+    STAMP(2);
     if (any) clip_and_emit(P, D, poly[threadIdx.x], c[0], c[1], c[2], any, prim);
+    STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,7 +430,8 @@ __device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
 
 // perspective-correct barycentrics of the pixel centre from the original clip-space triangle
 // (2-D homogeneous form relative to the pixel: valid for w <= 0 vertices, no clipped attributes needed)
-__device__ __forceinline__ void barycentrics(const DrawDesc& D, const f4 c[3], float pxc, float pyc, float b[3]) {
+template <bool FAST>
+__device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc, float pyc, float b[3]) {
     float ax[3], ay[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -412,11 +441,11 @@ __device__ __forceinline__ void barycentrics(const DrawDesc& D, const f4 c[3], f
     const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
     const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
     const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
-    const float inv = 1.0f / ((l0 + l1) + l2);
+    const float inv = FAST ? __builtin_amdgcn_rcpf((l0 + l1) + l2) : 1.0f / ((l0 + l1) + l2);
     b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
 }
 
-__device__ __forceinline__ f4 shade_triangle_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
+__device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; f3 col[3];
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
@@ -426,12 +455,12 @@ __device__ __forceinline__ f4 shade_triangle_program(const DrawDesc& D, uint32_t
         col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
     }
     float b[3];
-    barycentrics(D, c, pxc, pyc, b);
+    barycentrics<true>(D, c, pxc, pyc, b);   // no pow downstream: 1-ulp rcp is far inside the colour bound
     const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
     return {o.x, o.y, o.z, 1.0f};
 }
 
-__device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tri, float pxc, float pyc) {
+__device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; Varyings vv[3];
     const bool full = D.program == 2;
 #pragma unroll
@@ -441,22 +470,23 @@ __device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tr
         f3 world;
         c[k] = vs_position(D, vidx, &world);
         const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
-        const f3 N = normalize3(mat3_mul(D.object + 16, n));                // vertex/model.hlsl:51
+        const f3 N = normalize3(mat3_mul(cf(D.object) + 16, n));                // vertex/model.hlsl:51
         vv[k].world = world; vv[k].normal = N;
         if (full) {
             const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
             const float tw = ldf(v, 44);
-            f3 T = normalize3(mat3_mul(D.object, t));                       // :52
+            f3 T = normalize3(mat3_mul(cf(D.object), t));                       // :52
             T = normalize3(sub3(T, scale3(N, dot3(T, N))));                 // :55
             vv[k].tangent = T; vv[k].bitangent = scale3(cross3(N, T), tw);   // :58
             vv[k].u = ldf(v, 24); vv[k].v = ldf(v, 28);
         }
     }
     float b[3];
-    barycentrics(D, c, pxc, pyc, b);
+    barycentrics<false>(D, c, pxc, pyc, b);
     const f3 worldPos = interp3(b, vv[0].world, vv[1].world, vv[2].world);
     const f3 Nv = interp3(b, vv[0].normal, vv[1].normal, vv[2].normal);
-    const f3 camPos = {D.camera[48], D.camera[49], D.camera[50]};          // cameraPosition @192 B
+    const CFloatPtr cam = cf(D.camera);
+    const f3 camPos = {cam[48], cam[49], cam[50]};          // cameraPosition @192 B
     const f3 V = normalize3(sub3(camPos, worldPos));
     f3 N = normalize3(Nv);
 
@@ -472,8 +502,8 @@ __device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tr
     // pixel/model_full.hlsl:85-150
     const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
-    const f4 baseColor = {ldf(D.material, 0), ldf(D.material, 4), ldf(D.material, 8), ldf(D.material, 12)};
-    const float roughness = ldf(D.material, 20), ao = ldf(D.material, 24);
+    const f4 baseColor = {ldcf(cb(D.material), 0), ldcf(cb(D.material), 4), ldcf(cb(D.material), 8), ldcf(cb(D.material), 12)};
+    const float roughness = ldcf(cb(D.material), 20), ao = ldcf(cb(D.material), 24);
     const f4 albedoSample = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
     const f3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
     const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
@@ -489,20 +519,20 @@ __device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tr
     f3 lighting = {0.0f, 0.0f, 0.0f};
     const float shininess = roughness_to_shininess(roughness);
     {   // CalculateDirectionalLight lights.hlsli:166-179 (HLSL DirectionalLight layout :17-23)
-        const f3 dir = {ldf(D.lights, 0), ldf(D.lights, 4), ldf(D.lights, 8)};
-        const float intensity = ldf(D.lights, 12);
-        const f3 color = {ldf(D.lights, 16), ldf(D.lights, 20), ldf(D.lights, 24)};
+        const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
+        const float intensity = ldcf(cb(D.lights), 12);
+        const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
         const f3 L = normalize3({-dir.x, -dir.y, -dir.z});
         lighting = add3(lighting, blinn_phong(L, V, N, scale3(color, intensity), albedo, shininess));
     }
-    const uint32_t numPoint = D.point_lights ? ldu(D.lights, 32) : 0u;
-    const uint32_t numSpot = D.spot_lights ? ldu(D.lights, 36) : 0u;
+    const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
+    const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
     for (uint32_t i = 0; i < numPoint; i++) {                                // CalculatePointLight :182-199
-        const uint8_t* Lp = D.point_lights + 32u * i;
-        const f3 pos = {ldf(Lp, 0), ldf(Lp, 4), ldf(Lp, 8)};
-        const float radius = ldf(Lp, 12);
-        const f3 color = {ldf(Lp, 16), ldf(Lp, 20), ldf(Lp, 24)};
-        const float intensity = ldf(Lp, 28);
+        const CBytePtr Lp = cb(D.point_lights) + 32u * i;
+        const f3 pos = {ldcf(Lp, 0), ldcf(Lp, 4), ldcf(Lp, 8)};
+        const float radius = ldcf(Lp, 12);
+        const f3 color = {ldcf(Lp, 16), ldcf(Lp, 20), ldcf(Lp, 24)};
+        const float intensity = ldcf(Lp, 28);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
         const f3 L = scale3(lv, 1.0f / dist);
@@ -510,13 +540,13 @@ __device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tr
         lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
     }
     for (uint32_t j = 0; j < numSpot; j++) {                                 // CalculateSpotLight :202-231
-        const uint8_t* Ls = D.spot_lights + 48u * j;
-        const f3 pos = {ldf(Ls, 0), ldf(Ls, 4), ldf(Ls, 8)};
-        const float innerCos = ldf(Ls, 12);
-        const f3 sdir = {ldf(Ls, 16), ldf(Ls, 20), ldf(Ls, 24)};
-        const float outerCos = ldf(Ls, 28);
-        const f3 color = {ldf(Ls, 32), ldf(Ls, 36), ldf(Ls, 40)};
-        const float intensity = ldf(Ls, 44);
+        const CBytePtr Ls = cb(D.spot_lights) + 48u * j;
+        const f3 pos = {ldcf(Ls, 0), ldcf(Ls, 4), ldcf(Ls, 8)};
+        const float innerCos = ldcf(Ls, 12);
+        const f3 sdir = {ldcf(Ls, 16), ldcf(Ls, 20), ldcf(Ls, 24)};
+        const float outerCos = ldcf(Ls, 28);
+        const f3 color = {ldcf(Ls, 32), ldcf(Ls, 36), ldcf(Ls, 40)};
+        const float intensity = ldcf(Ls, 44);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
         const f3 L = scale3(lv, 1.0f / dist);
@@ -535,7 +565,7 @@ __device__ __forceinline__ f4 shade_model_program(const DrawDesc& D, uint32_t tr
 // a9: sRGB OETF + UNORM8, BGRA byte order (swapchain.rs:561-570)
 __device__ __forceinline__ uint32_t srgb8(float c) {
     c = saturatef(c);
-    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * fpow(c, 1.0f / 2.4f) - 0.055f;
+    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * __builtin_amdgcn_exp2f((1.0f / 2.4f) * __builtin_amdgcn_logf(c)) - 0.055f;
     e = saturatef(e);
     return (uint32_t)rintf(e * 255.0f);
 }
@@ -555,6 +585,13 @@ __device__ __forceinline__ RecRegs load_rec(const uint4* lds_rec, uint32_t j) {
     RecRegs r;
     r.w0 = lds_rec[j * 4u + 0]; r.w1 = lds_rec[j * 4u + 1]; r.w2 = lds_rec[j * 4u + 2]; r.w3 = lds_rec[j * 4u + 3];
     return r;
+}
+
+// d = a * b + c with 24-bit signed a, b (full-rate integer multiply-add)
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 
 // 48-bit product of two signed 24-bit values
@@ -629,9 +666,9 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
     const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
     const uint32_t idk = r.w3.z;
     const uint32_t m = __builtin_amdgcn_readfirstlane(r.w3.w);
-    const int32_t s0 = (int32_t)r.w0.x + __mul24(A0, ix0) + __mul24(B0, iy0);
-    const int32_t s1 = (int32_t)r.w0.y + __mul24(A1, ix0) + __mul24(B1, iy0);
-    const int32_t s2 = (int32_t)r.w0.z + __mul24(A2, ix0) + __mul24(B2, iy0);
+    const int32_t s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)r.w0.x));
+    const int32_t s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)r.w0.y));
+    const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
     // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
     const bool boxed = (m & 0x80000000u) != 0;
@@ -730,13 +767,14 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         }
         __syncthreads();
         const uint32_t n = *lds_count;
+        if (base == 0) STAMP(5);
         if (n) raster_chunk<KEYED>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
     }
 }
 
 // PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws
 template <int PROGS, int KEYED>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PROGS == 2 ? 4 : 3))) void raster_kernel(const PassParams P) {
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5)) void raster_kernel(const PassParams P) {
     __shared__ uint4 lds_rec[RASTER_THREADS * 4];
     __shared__ uint32_t lds_box[RASTER_THREADS];
     __shared__ uint32_t lds_count;
@@ -751,6 +789,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
     const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
     const uint32_t qmask = qbit0 * 0x33u;
 
+    STAMP(0);
     // both counters are fetched up front so their latencies overlap
     const uint32_t count_raw = P.bin_count[tile];
     const uint32_t nbig_raw = *P.big_count;
@@ -765,11 +804,13 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
         init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
     }
 
+    STAMP(1);
     if (count) {
         raster_list<KEYED>(reinterpret_cast<const uint4*>(P.bin_recs) + (size_t)tile * P.bin_cap * 3u, count, lds_rec, lds_box,
                            &lds_count, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
         if (tid == 0) P.bin_count[tile] = 0;            // ready for the next scope that uses this workspace
     }
+    STAMP(2);
     if (tile == 0 && tid == 0) {
         *P.big_count_next = 0;                          // the next scope on this workspace appends to the other counter
         P.status[1] = nbig_raw;
@@ -778,6 +819,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
         raster_list<KEYED>(reinterpret_cast<const uint4*>(P.big_recs), nbig, lds_rec, lds_box, &lds_count, tx, ty, qmask, ix0,
                            iy0, fix0, fiy0, P, st, qbit0, tid, lane);
 
+    STAMP(3);
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
 #pragma unroll 1
     for (int b = 0; b < 4; b++) {
@@ -798,7 +840,9 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);
             const bool mine = mydraw == d;
             if (mine) {
-                const DrawDesc& D = P.draws[d];
+                // readfirstlane again: inside this branch the compiler knows mydraw == d and would otherwise
+                // substitute the per-lane value, turning every descriptor access into a vector load
+                DrawRef D = const_draws(P.draws)[__builtin_amdgcn_readfirstlane(mydraw)];
                 const uint32_t tri = prim - D.prim_base;
                 const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
                 if (PROGS == 1) col = shade_triangle_program(D, tri, pxc, pyc);
@@ -810,7 +854,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
         if (!inb) continue;
         if (!(none && P.color_load)) {
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
-            else reinterpret_cast<uint32_t*>(P.color)[pix] = pack_bgra8_srgb(col);
+            else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : pack_bgra8_srgb(col);
         }
         if (P.prim_out) P.prim_out[pix] = prim;
         if (P.depth && P.depth_store) {
@@ -818,6 +862,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
             P.depth[pix] = __uint_as_float(zb);
         }
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,5 +892,17 @@ hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t str
     else launch_raster_k<1>(P, programs, grid, stream);
     return hipGetLastError();
 }
+
+#ifdef MIRHI_STAMPS
+extern "C" int mirhi_debug_read_stamps(uint64_t* dst, uint32_t count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mirhi_debug_clear_stamps() {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(p, 0, sizeof(uint64_t) * 16384 * 8);
+}
+#endif
 
 }  // namespace mirhi
