@@ -445,20 +445,30 @@ __device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc
     b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
 }
 
+#pragma clang fp contract(fast)
+// vertex/triangle.hlsl + pixel/triangle.hlsl: clip = (pos, 1), colour pass-through.  No pow downstream, so FMA
+// contraction and the 1-ulp rcp stay ~1e-7 from the oracle (bound 1e-4).  With w = 1 the homogeneous
+// barycentrics reduce to ax_k = x_k * W/2 + (cx - px).
 __device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
-    f4 c[3]; f3 col[3];
+    float ax[3], ay[3]; f3 col[3];
+    const float tx = D.cx - pxc, ty = D.cy - pyc;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         const uint32_t vidx = fetch_index(D, 3u * tri + k);
         const uint8_t* v = D.vb + (size_t)vidx * D.stride;
-        c[k] = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};                      // vertex/triangle.hlsl:19-20
+        ax[k] = ldf(v, 0) * D.hw + tx;                                       // vertex/triangle.hlsl:19-20
+        ay[k] = ldf(v, 4) * D.hh + ty;
         col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
     }
-    float b[3];
-    barycentrics<true>(D, c, pxc, pyc, b);   // no pow downstream: 1-ulp rcp is far inside the colour bound
+    const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
+    const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
+    const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
+    const float inv = __builtin_amdgcn_rcpf((l0 + l1) + l2);
+    const float b[3] = {l0 * inv, l1 * inv, l2 * inv};
     const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
     return {o.x, o.y, o.z, 1.0f};
 }
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; Varyings vv[3];
@@ -578,7 +588,7 @@ __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c) {
 // ------------------------------------------------------------------------------------------------
 // raster kernel
 // ------------------------------------------------------------------------------------------------
-struct PixelState { uint32_t zk[4], idk[4]; };
+struct PixelState { uint32_t zk[4], idk[4]; };   // (depth key, id key) per owned pixel; lexicographic minimum wins
 struct RecRegs { uint4 w0, w1, w2, w3; };
 
 __device__ __forceinline__ RecRegs load_rec(const uint4* lds_rec, uint32_t j) {
@@ -658,7 +668,7 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
 // KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied).
-template <int KEYED>
+template <int KEYED, bool BOXED>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
                                               float fiy0, const PassParams& P, PixelState& st, uint32_t qbit0) {
     const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
@@ -671,7 +681,6 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
     const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
     // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
-    const bool boxed = (m & 0x80000000u) != 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const int bx = b & 1, by = b >> 1;
@@ -680,19 +689,21 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
         const int32_t S1 = s1 + (A1 * bx + B1 * by) * BLOCK;
         const int32_t S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
         bool inside = (S0 | S1 | S2) >= 0;
-        if (boxed) {
+        if (BOXED) {
             const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
             inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
                      iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
         }
         const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
-        float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
-        z = z > 0.0f ? (z < 1.0f ? z : 1.0f) : 0.0f;
-        uint32_t zk = __float_as_uint(z);
+        const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+        // clamp to [0,1]: v_med3_f32 returns min3 = 0 when z is NaN; the mask turns a -0 result into +0
+        uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
         if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
         const uint64_t key = ((uint64_t)zk << 32) | idk;
         const uint64_t cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
-        if (inside && key < cur) { st.zk[b] = zk; st.idk[b] = idk; }
+        const bool upd = inside && key < cur;
+        st.zk[b] = upd ? zk : st.zk[b];
+        st.idk[b] = upd ? idk : st.idk[b];
     }
 }
 
@@ -705,15 +716,21 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
     for (uint32_t g = 0; g < n; g += 64u) {
         const uint32_t j = g + lane;
         const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
-        uint64_t bits = __ballot((mymask & qmask) != 0u);
-        if (!bits) continue;
+        const bool rel = (mymask & qmask) != 0u, boxed = (mymask & 0x80000000u) != 0u;
+        uint64_t bits = __ballot(rel && !boxed);
         while (bits) {
             const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
             bits &= bits - 1;
             const RecRegs cur = load_rec(lds_rec, cur_j);
-            uint32_t box = 0;
-            if (__builtin_amdgcn_readfirstlane(cur.w3.w) & 0x80000000u) box = lds_box[cur_j];
-            raster_record<KEYED>(cur, box, ix0, iy0, fix0, fiy0, P, st, qbit0);
+            raster_record<KEYED, false>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
+        }
+        // scissor-cut triangles (rare) run in their own loop with the per-pixel box test
+        uint64_t bbits = __ballot(rel && boxed);
+        while (bbits) {
+            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bbits) - 1);
+            bbits &= bbits - 1;
+            const RecRegs cur = load_rec(lds_rec, cur_j);
+            raster_record<KEYED, true>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
         }
     }
 }
