@@ -29,10 +29,13 @@ namespace mirhi {
 // Diagnostic build only (build.py --stamps -> libmirhi_stamps.so): per-wave s_memtime stamps at phase
 // boundaries, written to a buffer nothing else reads.  Never compiled into libmirhi.so.
 __device__ uint64_t g_stamps[16384 * 8];
+__device__ uint64_t g_stamps_geo[16384 * 4];
+#define GSTAMP(k) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 16384u) g_stamps_geo[blockIdx.x * 4u + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
     if (wv < 16384u) g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define GSTAMP(k) do {} while (0)
 #endif
 
 struct f3 { float x, y, z; };
@@ -200,38 +203,40 @@ __device__ __forceinline__ void bin_triangle(const PassParams& P, bool valid, co
     }
     const bool binned = valid && !spill;
     const uint32_t tile0 = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
-    uint32_t raw[MAX_BIN_SPAN * MAX_BIN_SPAN];
-    uint32_t uniform_bits = 0;
+    // Phase 1: reserve a slot in every overlapped tile's bin.  No result is consumed in this phase, so all
+    // atomics of a lane are in flight together.  If the wave's triangles are spatially coherent (mesh order:
+    // many lanes hit the same tile), lanes targeting the same tile are grouped and the group's first lane reserves
+    // the whole range with ONE returning atomic (up to GROUP_ROUNDS distinct tiles per slot).  Grouping stops at the
+    // first single-lane group (incoherent input such as random triangles would only serialise its atomics);
+    // the remaining lanes reserve individually.
+    constexpr int NSLOT = MAX_BIN_SPAN * MAX_BIN_SPAN, GROUP_ROUNDS = 8, GROUP_MIN = 2;
+    uint32_t raw[NSLOT];       // atomic result (held by the reserving lane)
+    uint32_t who[NSLOT];       // reserving lane | rank within its group << 8
 #pragma unroll
-    for (int k = 0; k < MAX_BIN_SPAN * MAX_BIN_SPAN; k++) {
+    for (int k = 0; k < NSLOT; k++) {
         const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
         const bool has = binned && kx < ntx && ky < nty;
-        const uint64_t hm = __ballot(has);
-        raw[k] = 0;
-        if (hm) {
-            const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
-            const int leader = __ffsll((long long)hm) - 1;
+        const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
+        raw[k] = 0; who[k] = lane;
+        uint64_t rem = __ballot(has);
+        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
+            const int leader = __ffsll((long long)rem) - 1;
             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-            const bool uni = __ballot(has && tile == t0) == hm;
-            if (uni) {
-                uniform_bits |= 1u << k;
-                if ((int)lane == leader) raw[k] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(hm));
-            } else if (has) {
-                raw[k] = atomicAdd(&P.bin_count[tile], 1u);
-            }
+            const uint64_t grp = __ballot(has && tile == t0) & rem;
+            if (__popcll(grp) < GROUP_MIN) break;               // incoherent: fall through to individual atomics
+            if (has && tile == t0 && ((rem >> lane) & 1ull)) who[k] = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
+            if ((int)lane == leader) raw[k] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
+            rem &= ~grp;
         }
+        if (has && ((rem >> lane) & 1ull)) raw[k] = atomicAdd(&P.bin_count[tile], 1u);   // ungrouped lanes
     }
+    // Phase 2: copy the record into each reserved slot
 #pragma unroll
-    for (int k = 0; k < MAX_BIN_SPAN * MAX_BIN_SPAN; k++) {
+    for (int k = 0; k < NSLOT; k++) {
         const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
         const bool has = binned && kx < ntx && ky < nty;
-        const uint64_t hm = __ballot(has);
-        if (!hm) continue;
-        uint32_t slot = raw[k];
-        if (uniform_bits & (1u << k)) {
-            const int leader = __ffsll((long long)hm) - 1;
-            slot = (uint32_t)__builtin_amdgcn_readlane((int)raw[k], leader) + (uint32_t)__popcll(hm & lt);
-        }
+        if (!__ballot(has)) continue;
+        const uint32_t slot = (uint32_t)__shfl((int)raw[k], (int)(who[k] & 0xFFu)) + (who[k] >> 8);
         if (has) {
             if (slot < P.bin_cap) {
                 const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
@@ -277,6 +282,7 @@ __device__ __forceinline__ uint32_t outcode_view(f4 c) {
 // kernel that touches scratch pays ~5 us per launch on this part).  Every resulting fan triangle goes to
 // the big list (the raster kernel builds its tile records), so this path needs no binning code.
 constexpr int CLIP_MAX_VERTS = 10;     // 3 + one per plane (near, far, 4 guard-band planes) = 9
+constexpr int CLIP_BATCH = 8;          // lanes clipping concurrently per wave (LDS polygon slots)
 
 __device__ __forceinline__ void clip_and_emit(const PassParams& P, DrawRef D, f4 (*poly)[CLIP_MAX_VERTS],
                                               f4 c0, f4 c1, f4 c2, uint32_t any, uint32_t prim) {
@@ -320,8 +326,8 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
 // one wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
 // and pipeline-state word) is wave-uniform and lives in SGPRs
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
-    __shared__ f4 poly[GEOM_THREADS][2][CLIP_MAX_VERTS];
-    STAMP(0);
+    __shared__ f4 poly[CLIP_BATCH][2][CLIP_MAX_VERTS];   // 2.5 KB: clipping lanes take turns, 8 at a time
+    GSTAMP(0);
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     uint32_t lo = 0, hi = P.num_draws;
     while (hi - lo > 1) {
@@ -344,11 +350,17 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             if (any == 0) valid = setup_triangle(P, D, c, prim, t);
         }
     }
-    STAMP(1);
+    GSTAMP(1);
     bin_triangle(P, valid, t);
-    STAMP(2);
-    if (any) clip_and_emit(P, D, poly[threadIdx.x], c[0], c[1], c[2], any, prim);
-    STAMP(3);
+    GSTAMP(2);
+    uint64_t todo = __ballot(any != 0);
+    while (todo) {                                   // rare: triangles crossing the near / far / guard planes
+        const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << (threadIdx.x & 63u)) - 1ull));
+        const bool mine = any != 0 && ((todo >> (threadIdx.x & 63u)) & 1ull) && rank < CLIP_BATCH;
+        if (mine) clip_and_emit(P, D, poly[rank], c[0], c[1], c[2], any, prim);
+        todo &= ~__ballot(mine);
+    }
+    GSTAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -913,6 +925,9 @@ hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t str
 #ifdef MIRHI_STAMPS
 extern "C" int mirhi_debug_read_stamps(uint64_t* dst, uint32_t count) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mirhi_debug_read_geo_stamps(uint64_t* dst, uint32_t count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_geo), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
 }
 extern "C" int mirhi_debug_clear_stamps() {
     void* p = nullptr;
