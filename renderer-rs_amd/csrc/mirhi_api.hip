@@ -122,6 +122,7 @@ struct mirhi_pipeline {
 struct RecordedPass {
     mirhi_rendering_info info;
     std::vector<DrawDesc> draws;
+    std::vector<uint64_t> draw_vb_bytes;   // bytes of the bound vertex buffer range per draw (vertex pre-pass extent)
     uint32_t total_tris = 0;
     bool key_set = false;
     uint32_t depth_test = 0, depth_compare = 0;
@@ -133,11 +134,13 @@ struct Workspace {
     TileRec* bin_recs = nullptr; size_t bin_recs_bytes = 0;
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
+    VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
+    uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* status_host = nullptr;                             // pinned, device-mapped: [status bits, big-list length]
     uint32_t* status_dev = nullptr;                              // device view of status_host
     uint32_t* big_counts = nullptr;                              // two counters, used alternately (parity)
     uint32_t parity = 0;
-    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes; }
+    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes; }
 };
 
 enum CmdState { CMD_INITIAL = 0, CMD_RECORDING = 1, CMD_EXECUTABLE = 2 };
@@ -538,6 +541,8 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.bin_recs) (void)hipFree(w.bin_recs);
     if (w.counters) (void)hipFree(w.counters);
     if (w.big_recs) (void)hipFree(w.big_recs);
+    if (w.vs_jobs) (void)hipFree(w.vs_jobs);
+    if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.status_host) (void)hipHostFree(w.status_host);
     w = Workspace();
 }
@@ -765,6 +770,7 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     d.scissor_partial = (sx0 > 0 || sy0 > 0 || sx1 < (int64_t)ci->width - 1 || sy1 < (int64_t)ci->height - 1) ? 1u : 0u;
     if (sx0 > sx1 || sy0 > sy1) return MIRHI_OK;    // empty scissor: nothing can be covered
     pass.draws.push_back(d);
+    pass.draw_vb_bytes.push_back(vb_bytes);
     pass.total_tris += tri_count;
     return MIRHI_OK;
 }
@@ -857,6 +863,45 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     w.big_counts = w.counters + max_tiles;
     w.parity = 0;
 
+    // vertex pre-pass jobs: one per distinct (vertex range, camera, object, program class) of each scope
+    struct HostJob { VsJob j; size_t out_off; };
+    std::vector<std::vector<HostJob>> pass_jobs(cmd->passes.size());
+    size_t vs_bytes_max = 0, jobs_total = 0;
+    for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
+        RecordedPass& pass = cmd->passes[pi];
+        size_t off = 0; uint32_t slots = 0;
+        for (size_t di = 0; di < pass.draws.size(); di++) {
+            DrawDesc& dd = pass.draws[di];
+            dd.vs_words = 0; dd.vs_out = nullptr;
+            if (dd.program == MIRHI_PROGRAM_TRIANGLE) continue;
+            const uint32_t words = dd.program == MIRHI_PROGRAM_MODEL_FULL ? 5u : 3u;
+            const uint64_t vbb = pass.draw_vb_bytes[di];
+            const uint32_t count = vbb >= 48 ? (uint32_t)((vbb - 48) / dd.stride + 1) : 0u;
+            size_t found = SIZE_MAX;
+            for (size_t j = 0; j < pass_jobs[pi].size(); j++) {
+                const VsJob& J = pass_jobs[pi][j].j;
+                if (J.vb == dd.vb && J.camera == dd.camera && J.object == dd.object && J.stride == dd.stride && J.words >= words && J.count >= count) { found = j; break; }
+            }
+            if (found == SIZE_MAX) {
+                HostJob hj{};
+                hj.j.vb = dd.vb; hj.j.camera = dd.camera; hj.j.object = dd.object; hj.j.stride = dd.stride; hj.j.count = count;
+                hj.j.words = words; hj.j.slot_base = slots; hj.out_off = off;
+                slots += (count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS;
+                off += ((size_t)count * words * 16 + 255) & ~(size_t)255;
+                pass_jobs[pi].push_back(hj);
+                found = pass_jobs[pi].size() - 1;
+            }
+            dd.vs_words = pass_jobs[pi][found].j.words;
+            dd.vs_out = (const void*)(uintptr_t)(pass_jobs[pi][found].out_off + 1);   // offset + 1, patched to a pointer below
+        }
+        if (off > vs_bytes_max) vs_bytes_max = off;
+        jobs_total += pass_jobs[pi].size();
+    }
+    if ((r = grow(&w.vs_out, &w.vs_out_bytes, vs_bytes_max ? vs_bytes_max : 256)) != MIRHI_OK) return r;
+    if ((r = grow(&w.vs_jobs, &w.vs_jobs_bytes, (jobs_total ? jobs_total : 1) * sizeof(VsJob))) != MIRHI_OK) return r;
+    std::vector<VsJob> all_jobs;
+    all_jobs.reserve(jobs_total);
+
     // upload draw descriptors, build per-pass parameters
     std::vector<DrawDesc> all;
     all.reserve(total_draws);
@@ -891,6 +936,16 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
+        P.vs_jobs = w.vs_jobs + all_jobs.size();
+        P.num_vs_jobs = (uint32_t)pass_jobs[pi].size();
+        P.vs_total_slots = 0;
+        for (HostJob& hj : pass_jobs[pi]) {
+            hj.j.out = w.vs_out + hj.out_off;
+            P.vs_total_slots = hj.j.slot_base + (hj.j.count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS;
+            all_jobs.push_back(hj.j);
+        }
+        for (DrawDesc& dd : pass.draws)
+            if (dd.vs_words) dd.vs_out = w.vs_out + ((size_t)(uintptr_t)dd.vs_out - 1);
         uint32_t slots = 0;
         for (DrawDesc& dd : pass.draws) { dd.slot_base = slots; slots += (dd.tri_count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS; }
         P.total_slots = slots;
@@ -903,6 +958,9 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     }
     if (!all.empty()) {
         HIP_TRY(hipMemcpyAsync(w.draws, all.data(), all.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, stream));
+    }
+    if (!all_jobs.empty()) {
+        HIP_TRY(hipMemcpyAsync(w.vs_jobs, all_jobs.data(), all_jobs.size() * sizeof(VsJob), hipMemcpyHostToDevice, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
     dev->stats.workspace_bytes = w.bytes();
@@ -941,6 +999,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             c->ws.parity ^= 1u;
             EventPair ev{};
             if (dev->profiling) { mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r; }
+            HIP_TRY(launch_vertex(P, stream));
             HIP_TRY(launch_geometry(P, stream));
             if (dev->profiling) {
                 HIP_TRY(hipEventRecord(ev.b, stream));

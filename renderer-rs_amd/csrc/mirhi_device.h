@@ -49,9 +49,25 @@ struct DrawDesc {
     float    gx, gy;              // guard-band plane factors
     int32_t  sx0, sy0, sx1, sy1;  // inclusive scissor (already clamped to render area and extent)
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
-    uint32_t pad[1];
+    uint32_t vs_words;            // 16-byte words per shaded vertex (3 MODEL, 5 MODEL_FULL, 0 = no vertex pre-pass)
+    const void* vs_out;           // shaded vertices of this draw's vertex buffer (see VsJob), indexed like the vertex buffer
+    uint64_t pad2;
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");
+
+// Vertex-shader pre-pass (vertex/model.hlsl:39-68 run once per vertex, as a GPU's vertex stage does, instead of three
+// times per shaded pixel): one job per distinct (vertex buffer range, camera, object, program class) of a scope.
+// Shaded vertex = vs_words 16-byte words:
+//   w0 = clip position            w1 = { world.xyz, N.x }        w2 = { N.y, N.z, u, v }
+//   MODEL_FULL adds               w3 = { T.xyz, B.x }            w4 = { B.y, B.z, 0, 0 }
+struct VsJob {
+    const uint8_t* vb;
+    const float*   camera;
+    const float*   object;
+    void*          out;
+    uint32_t stride, count, slot_base, words;
+};
+static_assert(sizeof(VsJob) == 48, "VsJob is 48 bytes");
 
 // Screen-space triangle record, 12 dwords = three 16-byte words.  Written once per overlapped tile into
 // that tile's bin (and once into the big list for triangles that span more than 4x4 tiles, were clipped,
@@ -72,6 +88,7 @@ struct PassParams {
     uint32_t num_draws, total_tris;
     uint32_t total_slots;             // geometry-kernel lanes (every draw padded to a multiple of 64)
     const DrawDesc* draws;
+    const VsJob* vs_jobs; uint32_t num_vs_jobs, vs_total_slots;
     // depth key (DESIGN.md "Depth key"): zk = (bits(z) ^ zflip) & zmask ; idk = idflip ? MAX-id : id
     uint32_t zflip, zmask, idflip;
     uint32_t strict;                  // compare op is LESS / GREATER (ties with the stored depth fail)

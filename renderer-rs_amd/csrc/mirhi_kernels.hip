@@ -323,6 +323,42 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
     return lo;
 }
 
+// ------------------------------------------------------------------------------------------------
+// a4: vertex-shader pre-pass for the MODEL / MODEL_FULL programs (vertex/model.hlsl:39-68)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams P) {
+    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    const MIRHI_CONST VsJob* jobs = (const MIRHI_CONST VsJob*)(uintptr_t)P.vs_jobs;
+    uint32_t lo = 0, hi = P.num_vs_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].slot_base <= slot0) lo = mid; else hi = mid;
+    }
+    const MIRHI_CONST VsJob& J = jobs[lo];
+    const uint32_t vidx = slot0 - J.slot_base + threadIdx.x;
+    if (vidx >= J.count) return;
+    const uint8_t* v = J.vb + (size_t)vidx * J.stride;
+    const CFloatPtr model = cf(J.object);
+    const f4 p = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};
+    const f4 w = mat4_mul(model, p);                                         // vertex/model.hlsl:44
+    const f4 c = mat4_mul(cf(J.camera) + 32, w);                             // :48
+    const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
+    const f3 N = normalize3(mat3_mul(model + 16, n));                        // :51
+    uint4* out = reinterpret_cast<uint4*>(J.out) + (size_t)vidx * J.words;
+    out[0] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
+    out[1] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(N.x));
+    out[2] = make_uint4(__float_as_uint(N.y), __float_as_uint(N.z), ldu(v, 24), ldu(v, 28));
+    if (J.words == 5) {
+        const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
+        const float tw = ldf(v, 44);
+        f3 T = normalize3(mat3_mul(model, t));                               // :52
+        T = normalize3(sub3(T, scale3(N, dot3(T, N))));                      // :55 Gram-Schmidt
+        const f3 B = scale3(cross3(N, T), tw);                               // :58
+        out[3] = make_uint4(__float_as_uint(T.x), __float_as_uint(T.y), __float_as_uint(T.z), __float_as_uint(B.x));
+        out[4] = make_uint4(__float_as_uint(B.y), __float_as_uint(B.z), 0u, 0u);
+    }
+}
+
 // one wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
 // and pipeline-state word) is wave-uniform and lives in SGPRs
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
@@ -343,7 +379,15 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
     f4 c[3];
     if (tri < D.tri_count) {
 #pragma unroll
-        for (uint32_t k = 0; k < 3; k++) c[k] = vs_position(D, fetch_index(D, 3u * tri + k), nullptr);
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t vidx = fetch_index(D, 3u * tri + k);
+            if (D.vs_words) {                      // MODEL programs: clip position from the vertex pre-pass
+                const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[(size_t)vidx * D.vs_words];
+                c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+            } else {
+                c[k] = vs_position(D, vidx, nullptr);
+            }
+        }
         const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
         if (!(o0 & o1 & o2)) {
             any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
@@ -487,20 +531,17 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
     const bool full = D.program == 2;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint32_t vidx = fetch_index(D, 3u * tri + k);
-        const uint8_t* v = D.vb + (size_t)vidx * D.stride;
-        f3 world;
-        c[k] = vs_position(D, vidx, &world);
-        const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
-        const f3 N = normalize3(mat3_mul(cf(D.object) + 16, n));                // vertex/model.hlsl:51
-        vv[k].world = world; vv[k].normal = N;
+        // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)fetch_index(D, 3u * tri + k) * D.vs_words;
+        const uint4 w0 = sv[0], w1 = sv[1], w2 = sv[2];
+        c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+        vv[k].world = {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)};
+        vv[k].normal = {__uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y)};
         if (full) {
-            const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
-            const float tw = ldf(v, 44);
-            f3 T = normalize3(mat3_mul(cf(D.object), t));                       // :52
-            T = normalize3(sub3(T, scale3(N, dot3(T, N))));                 // :55
-            vv[k].tangent = T; vv[k].bitangent = scale3(cross3(N, T), tw);   // :58
-            vv[k].u = ldf(v, 24); vv[k].v = ldf(v, 28);
+            const uint4 w3 = sv[3], w4 = sv[4];
+            vv[k].u = __uint_as_float(w2.z); vv[k].v = __uint_as_float(w2.w);
+            vv[k].tangent = {__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z)};
+            vv[k].bitangent = {__uint_as_float(w3.w), __uint_as_float(w4.x), __uint_as_float(w4.y)};
         }
     }
     float b[3];
@@ -897,6 +938,12 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
+hipError_t launch_vertex(const PassParams& P, hipStream_t stream) {
+    if (P.vs_total_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), 0, stream, P);
+    return hipGetLastError();
+}
+
 hipError_t launch_geometry(const PassParams& P, hipStream_t stream) {
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t blocks = P.total_slots / GEOM_THREADS;
