@@ -46,6 +46,8 @@ def parse_args():
                          "(MAX_FRAMES_IN_FLIGHT) + 1 swapchain image")
     ap.add_argument("--profile-pass-only", action="store_true",
                     help="only the isolated per-kernel timing pass (one frame at a time): the command profiled with rocprofv3")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only for single-box rehearsals")
+    ap.add_argument("--no-split-extra", action="store_true", help="N>1: skip the secondary tile-row-split measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -70,6 +72,47 @@ def cpu_baseline(scene, seconds: float):
             "sample": f"{frames} whole frames of the same workload in {dt:.1f} s (oracle/mirhi_oracle.c, {cores} row-band threads)"}
 
 
+def tile_split_measurement(m, multigpu, torch, dist, dev0, rank, world, local_rank, args, barrier):
+    """SURVEY 8e / BASELINE configs[3]: ONE frame (1M triangles, 3840x2160) split by screen-tile rows across the ranks,
+    the bands all-gathered over RCCL/xGMI every frame.  Strong scaling of a single frame; reported beside the primary."""
+    import time as _t
+    scene = m.scenes.heightfield_grid()
+    dev = m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    dev.set_tile_split(rank, world)
+    keep = []
+
+    def wrap(device, usage, arr):
+        t = torch.from_numpy(arr.copy()).cuda()
+        keep.append(t)
+        return m.Buffer.wrap(device, usage, t.data_ptr(), t.numel())
+
+    frame = torch.zeros((multigpu.padded_rows(scene.height, world), scene.width, 4), dtype=torch.uint8, device="cuda")
+    target = m.Image(dev, scene.width, scene.height, m.Format.B8G8R8A8_SRGB, device_ptr=frame.data_ptr())
+    res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB, color_image=target, wrap_buffers=wrap)
+    steps = max(10, min(200, args.steps))
+
+    def step():
+        res.render()
+        multigpu.all_gather_bands(frame, rank, world, via_host=(args.backend == "gloo"))
+
+    for _ in range(5):
+        step()
+    barrier()
+    t0 = _t.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = _t.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    res.destroy()
+    dev.destroy()
+    return {"workload": "c4: 1M-triangle grid, 3840x2160, tile-row split + in-place all-gather of BGRA8 bands",
+            "value": round(scene.num_triangles * steps / dt / 1e6, 3), "unit": "Mtris/s", "ms_per_frame": round(1e3 * dt / steps, 4),
+            "steps": steps, "scaling": "strong", "n_gpus": world}
+
+
 def main():
     args = parse_args()
     import torch
@@ -83,11 +126,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: there is no CPU fallback for the measured path")
+    if "MIRHI_BENCH_FORCE_DEVICE" in os.environ:          # rehearsal of N > 1 on a one-GPU box (gloo)
+        local_rank = int(os.environ["MIRHI_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
@@ -138,7 +186,7 @@ def main():
         counter[0] += 1
         slots[i].render()
         if split:
-            multigpu.all_gather_bands(frames[i], rank, world)
+            multigpu.all_gather_bands(frames[i], rank, world, via_host=(args.backend == "gloo"))
 
     for _ in range(args.warmup):
         step()
@@ -163,6 +211,13 @@ def main():
     geo_ms, geo_n = dev.kernel_time(m.Kernel.GEOMETRY)
     ras_ms, ras_n = dev.kernel_time(m.Kernel.RASTER)
     dev.set_profiling(False)
+
+    split_extra = None
+    if world > 1 and not split and not args.no_split_extra and not args.profile_pass_only:
+        try:
+            split_extra = tile_split_measurement(m, multigpu, torch, dist, dev, rank, world, local_rank, args, barrier)
+        except Exception as e:          # never let the secondary measurement take the primary line down
+            split_extra = {"error": repr(e)}
 
     frames_total = args.steps * (1 if split else world)
     tris = scene.num_triangles
@@ -195,6 +250,8 @@ def main():
                          "how": "hipEvent pairs on the submit stream around every launch; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
             "workspace_mb": round(stats.workspace_bytes / 1e6, 1), "big_list": stats.last_big_list,
         }
+        if split_extra is not None:
+            out["tile_split"] = split_extra
         if not args.no_cpu_baseline and world == 1 and not args.profile_pass_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)

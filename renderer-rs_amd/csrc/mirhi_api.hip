@@ -136,11 +136,12 @@ struct Workspace {
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
+    uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
     uint32_t* status_host = nullptr;                             // pinned, device-mapped: [status bits, big-list length]
     uint32_t* status_dev = nullptr;                              // device view of status_host
     uint32_t* big_counts = nullptr;                              // two counters, used alternately (parity)
     uint32_t parity = 0;
-    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes; }
+    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes + flat_color_bytes; }
 };
 
 enum CmdState { CMD_INITIAL = 0, CMD_RECORDING = 1, CMD_EXECUTABLE = 2 };
@@ -543,6 +544,7 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.big_recs) (void)hipFree(w.big_recs);
     if (w.vs_jobs) (void)hipFree(w.vs_jobs);
     if (w.vs_out) (void)hipFree(w.vs_out);
+    if (w.flat_color) (void)hipFree(w.flat_color);
     if (w.status_host) (void)hipHostFree(w.status_host);
     w = Workspace();
 }
@@ -901,6 +903,13 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     if ((r = grow(&w.vs_jobs, &w.vs_jobs_bytes, (jobs_total ? jobs_total : 1) * sizeof(VsJob))) != MIRHI_OK) return r;
     std::vector<VsJob> all_jobs;
     all_jobs.reserve(jobs_total);
+    size_t flat_tris = 0;
+    for (auto& pass : cmd->passes) {
+        bool tri_prog = false;
+        for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
+        if (tri_prog && pass.info.color_image->format == MIRHI_FORMAT_B8G8R8A8_SRGB && pass.total_tris > flat_tris) flat_tris = pass.total_tris;
+    }
+    if (flat_tris && (r = grow(&w.flat_color, &w.flat_color_bytes, flat_tris * 4)) != MIRHI_OK) return r;
 
     // upload draw descriptors, build per-pass parameters
     std::vector<DrawDesc> all;
@@ -936,6 +945,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
+        {
+            bool tri_prog = false;
+            for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
+            P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
+        }
+        P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();
         P.num_vs_jobs = (uint32_t)pass_jobs[pi].size();
         P.vs_total_slots = 0;

@@ -106,6 +106,9 @@ struct PassParams {
     TileRec*  bin_recs; uint32_t* bin_count; uint32_t bin_cap;
     BigRec*   big_recs; uint32_t* big_count; uint32_t big_cap;
     uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
+    uint32_t* flat_color;             // per primitive: B8G8R8A8_SRGB colour if its three vertex colours are equal (TRIANGLE
+                                      // program, sRGB8 target), else 0; lets the resolve skip interpolation + OETF
+    uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
     uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
 };
 

@@ -359,6 +359,8 @@ __global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams P
     }
 }
 
+__device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
+
 // one wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
 // and pipeline-state word) is wave-uniform and lives in SGPRs
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
@@ -393,6 +395,15 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
             if (any == 0) valid = setup_triangle(P, D, c, prim, t);
         }
+    }
+    if (P.flat_color && D.program == 0 && (valid || any)) {
+        // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
+        const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
+        const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
+        const uint8_t* v2 = D.vb + (size_t)fetch_index(D, 3u * tri + 2u) * D.stride;
+        const uint32_t r = ldu(v0, 12), g = ldu(v0, 16), b = ldu(v0, 20);
+        const bool flat = r == ldu(v1, 12) && r == ldu(v2, 12) && g == ldu(v1, 16) && g == ldu(v2, 16) && b == ldu(v1, 20) && b == ldu(v2, 20);
+        P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
     }
     GSTAMP(1);
     bin_triangle(P, valid, t);
@@ -850,7 +861,16 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
     __shared__ uint32_t lds_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
-    const uint32_t tile = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, each XCD
+    // has its own L2).  Runs of G consecutive tiles go to the same XCD so neighbouring tiles -- which share triangle
+    // records, shaded vertices and texture footprints -- hit the same L2, while the runs stay interleaved across
+    // XCDs for load balance (one contiguous band per XCD measured 20-30 % slower on unevenly covered frames).
+    const uint32_t G = P.xcd_swizzle, ntiles = gridDim.x;
+    uint32_t tile = blockIdx.x;
+    if (G > 1u && ntiles % (8u * G) == 0u) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        tile = ((j / G) * 8u + xcd) * G + (j % G);
+    }
     const uint32_t tx = tile % P.tiles_x, ty = P.tile_row_begin + tile / P.tiles_x;
     const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
     const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
@@ -905,10 +925,12 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
         f4 col = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
         // waterfall over the draws present in this wave: the draw descriptor stays wave-uniform (scalar loads)
         const uint32_t mydraw = none ? 0xFFFFFFFFu : (P.num_draws > 1 ? find_draw(P, prim) : 0u);
-        uint64_t todo = __ballot(!none);
+        uint32_t flat = 0;
+        if (PROGS == 1 && P.flat_color && !none) flat = P.flat_color[prim];      // alpha is 255 whenever it is set
+        uint64_t todo = __ballot(!none && flat == 0u);
         while (todo) {
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);
-            const bool mine = mydraw == d;
+            const bool mine = mydraw == d && flat == 0u;
             if (mine) {
                 // readfirstlane again: inside this branch the compiler knows mydraw == d and would otherwise
                 // substitute the per-lane value, turning every descriptor access into a vector load
@@ -924,7 +946,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
         if (!inb) continue;
         if (!(none && P.color_load)) {
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
-            else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : pack_bgra8_srgb(col);
+            else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));
         }
         if (P.prim_out) P.prim_out[pix] = prim;
         if (P.depth && P.depth_store) {

@@ -37,14 +37,19 @@ def padded_rows(height: int, world: int) -> int:
     return rows_per_rank(height, world) * world
 
 
-def all_gather_bands(frame, rank: int, world: int, group=None):
+def all_gather_bands(frame, rank: int, world: int, group=None, via_host: bool = False):
     """In-place all-gather of the row bands. `frame` is a (padded_rows, W, C) tensor (any device);
-    rank r has rendered rows [r*per, (r+1)*per) and receives everyone else's."""
+    rank r has rendered rows [r*per, (r+1)*per) and receives everyone else's.  `via_host` stages through CPU
+    tensors (gloo rehearsals on a box without RCCL peers); the product path is the single RCCL collective."""
     import torch.distributed as dist
     per = frame.shape[0] // world
     assert per * world == frame.shape[0], "frame must have padded_rows(height, world) rows"
     mine = frame[rank * per:(rank + 1) * per]
-    if frame.is_cuda:
+    if frame.is_cuda and via_host:
+        host = frame.cpu()
+        all_gather_bands(host, rank, world, group=group)
+        frame.copy_(host)
+    elif frame.is_cuda:
         dist.all_gather_into_tensor(frame, mine, group=group)
     else:  # gloo (CPU tests): list form
         chunks = [frame[r * per:(r + 1) * per] for r in range(world)]
