@@ -950,6 +950,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
             P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
+        {   // triangle-parallel resolve of small records pays when tiles hold many triangles (meshes); sparse scopes keep
+            // the leaner pixel-parallel-only kernel.  MIRHI_TP_MAX_AREA overrides (0 = off) for A/B measurements.
+            const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
+            const bool dense = tiles && pass.total_tris / tiles >= 16;
+            P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 128u : 0u);
+        }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();
         P.num_vs_jobs = (uint32_t)pass_jobs[pi].size();

@@ -16,6 +16,8 @@ constexpr int TILE = 32;              // screen tile edge in pixels (one raster 
 constexpr int TILE_LOG2 = 5;
 constexpr int BLOCK = 8;              // coverage block edge (one wave-iteration covers 8x8 px)
 constexpr int RASTER_THREADS = 256;   // 4 waves; wave q owns the 16x16 quadrant q, 4 px per lane
+constexpr int RASTER_CHUNK = 192;     // triangle records staged per LDS pass (12 KB)
+constexpr int TP_MIN_LANES = 32;      // small records a wave must hold before it resolves them triangle-parallel
 constexpr int GEOM_THREADS = 64;
 constexpr int MAX_BIN_SPAN = 4;       // triangles spanning more than 4x4 tiles go to the big list
 constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay inside +-2^22 sub-pixels
@@ -108,6 +110,8 @@ struct PassParams {
     uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
     uint32_t* flat_color;             // per primitive: B8G8R8A8_SRGB colour if its three vertex colours are equal (TRIANGLE
                                       // program, sRGB8 target), else 0; lets the resolve skip interpolation + OETF
+    uint32_t tp_max_area;             // records whose pixel box inside the tile has at most this many pixels are resolved
+                                      // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
     uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
 };

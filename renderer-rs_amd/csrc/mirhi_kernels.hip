@@ -773,14 +773,14 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
 
 // all records of an LDS chunk: per 64 records one ballot builds the bitmap of records that touch this
 // wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
-template <int KEYED>
+template <int KEYED, int TP>
 __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
                                              int32_t ix0, int32_t iy0, float fix0, float fiy0, const PassParams& P,
                                              PixelState& st, uint32_t qbit0, uint32_t lane) {
     for (uint32_t g = 0; g < n; g += 64u) {
         const uint32_t j = g + lane;
         const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
-        const bool rel = (mymask & qmask) != 0u, boxed = (mymask & 0x80000000u) != 0u;
+        const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u;
         uint64_t bits = __ballot(rel && !boxed);
         while (bits) {
             const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
@@ -788,14 +788,48 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
             const RecRegs cur = load_rec(lds_rec, cur_j);
             raster_record<KEYED, false>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
         }
-        // scissor-cut triangles (rare) run in their own loop with the per-pixel box test
-        uint64_t bbits = __ballot(rel && boxed);
-        while (bbits) {
-            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bbits) - 1);
-            bbits &= bbits - 1;
-            const RecRegs cur = load_rec(lds_rec, cur_j);
-            raster_record<KEYED, true>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
+        if (!TP) {   // without the triangle-parallel path, scissor-cut triangles (rare) take the per-pixel box test here
+            uint64_t bbits = __ballot(rel && boxed);
+            while (bbits) {
+                const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bbits) - 1);
+                bbits &= bbits - 1;
+                const RecRegs cur = load_rec(lds_rec, cur_j);
+                raster_record<KEYED, true>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
+            }
         }
+    }
+}
+
+// Triangle-parallel resolve of ONE small record by the lane that built it: walks the record's pixel box inside the
+// tile and merges covered pixels into the tile's LDS key array with 64-bit ds_min.  For tiles holding many small
+// triangles this keeps all 64 lanes busy on different triangles, where the pixel-parallel loop above would spend a
+// full wave iteration per triangle with a handful of lanes covered.  Same integers, same depth FMAs, same keys.
+template <int KEYED>
+__device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, unsigned long long* lds_key, const PassParams& P) {
+    const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
+    const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
+    const float dxt = __uint_as_float(rec[2].y), dyt = __uint_as_float(rec[2].z), z0 = __uint_as_float(rec[2].w);
+    const float zx = __uint_as_float(rec[3].x), zy = __uint_as_float(rec[3].y);
+    const uint32_t idk = rec[3].z;
+    const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
+    const int32_t by0 = (int32_t)((box >> 16) & 0xFF), by1 = (int32_t)(box >> 24);
+    int32_t r0 = mad24(B0, by0, mad24(A0, bx0, (int32_t)rec[0].x));
+    int32_t r1 = mad24(B1, by0, mad24(A1, bx0, (int32_t)rec[0].y));
+    int32_t r2 = mad24(B2, by0, mad24(A2, bx0, (int32_t)rec[0].z));
+    for (int32_t iy = by0; iy <= by1; iy++) {
+        int32_t s0 = r0, s1 = r1, s2 = r2;
+        const float dy = (float)iy + dyt;
+        for (int32_t ix = bx0; ix <= bx1; ix++) {
+            if ((s0 | s1 | s2) >= 0) {
+                const float dx = (float)ix + dxt;
+                const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+                uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+                if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+                atomicMin(&lds_key[iy * TILE + ix], ((unsigned long long)zk << 32) | idk);
+            }
+            s0 += A0; s1 += A1; s2 += A2;
+        }
+        r0 += B0; r1 += B1; r2 += B2;
     }
 }
 
@@ -816,25 +850,41 @@ __device__ __forceinline__ void init_key(const PassParams& P, uint32_t px, uint3
 
 // Stages up to RASTER_THREADS triangle records of `list` (bin or big list) into LDS as tile records
 // (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
-template <int KEYED>
-__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec,
-                                            uint32_t* lds_box, uint32_t* lds_count, uint32_t tx, uint32_t ty,
+template <int KEYED, int TP>
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
+                                            uint32_t* lds_count, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             const PassParams& P, PixelState& st, uint32_t qbit0, uint32_t tid,
                                             uint32_t lane) {
     const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
-    for (uint32_t base = 0; base < n_total; base += RASTER_THREADS) {
+    for (uint32_t base = 0; base < n_total; base += RASTER_CHUNK) {
         if (tid == 0) *lds_count = 0;
         __syncthreads();
         const uint32_t i = base + tid;
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
-        if (i < n_total) {
+        if (tid < RASTER_CHUNK && i < n_total) {
             const uint4 w2 = list[(size_t)i * 3u + 2u];
             const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
             const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
             hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
             if (hit) hit = make_tile_rec(rec, box, list[(size_t)i * 3u], list[(size_t)i * 3u + 1u], w2, (int32_t)tx, (int32_t)ty);
+        }
+        bool small = false, boxed = false;
+        if (hit) {
+            // small (and all scissor-cut) records are resolved right here, triangle-parallel; the rest is staged
+            const uint32_t bw = ((box >> 8) & 0xFF) - (box & 0xFF) + 1u, bh = (box >> 24) - ((box >> 16) & 0xFF) + 1u;
+            small = bw * bh <= P.tp_max_area;
+            boxed = (rec[3].w & 0x80000000u) != 0u;
+        }
+        // Triangle-parallel only pays when the wave holds enough small records to keep its lanes busy (meshes of small
+        // triangles); a few stragglers in a sparse tile would serialise their pixel loops while 3 waves wait.
+        if (TP) {
+            const bool wave_tp = __popcll(__ballot(hit && small)) >= TP_MIN_LANES;
+            if (hit && (boxed || (small && wave_tp))) {
+                raster_small<KEYED>(rec, box, lds_key, P);
+                hit = false;
+            }
         }
         const uint64_t ball = __ballot(hit);
         uint32_t wbase = 0;
@@ -844,20 +894,23 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
             lds_rec[slot * 4u + 0] = rec[0]; lds_rec[slot * 4u + 1] = rec[1];
             lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
-            lds_box[slot] = box;
+            if (!TP) lds_box[slot] = box;
         }
         __syncthreads();
         const uint32_t n = *lds_count;
         if (base == 0) STAMP(5);
-        if (n) raster_chunk<KEYED>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
+        if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
     }
 }
 
 // PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws
-template <int PROGS, int KEYED>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5)) void raster_kernel(const PassParams P) {
-    __shared__ uint4 lds_rec[RASTER_THREADS * 4];
-    __shared__ uint32_t lds_box[RASTER_THREADS];
+// TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
+//     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
+template <int PROGS, int KEYED, int TP>
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams P) {
+    __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
+    __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
+    __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
     __shared__ uint32_t lds_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
@@ -886,6 +939,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
     const uint32_t count = count_raw < P.bin_cap ? count_raw : P.bin_cap;
     const uint32_t nbig = nbig_raw < P.big_cap ? nbig_raw : P.big_cap;
 
+    if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
     PixelState st;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -896,8 +950,8 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
 
     STAMP(1);
     if (count) {
-        raster_list<KEYED>(reinterpret_cast<const uint4*>(P.bin_recs) + (size_t)tile * P.bin_cap * 3u, count, lds_rec, lds_box,
-                           &lds_count, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
+        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(P.bin_recs) + (size_t)tile * P.bin_cap * 3u, count, lds_rec, lds_box,
+                           &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
         if (tid == 0) P.bin_count[tile] = 0;            // ready for the next scope that uses this workspace
     }
     STAMP(2);
@@ -906,10 +960,11 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
         P.status[1] = nbig_raw;
     }
     if (nbig)    // every tile tests every large / clipped / spilled triangle
-        raster_list<KEYED>(reinterpret_cast<const uint4*>(P.big_recs), nbig, lds_rec, lds_box, &lds_count, tx, ty, qmask, ix0,
+        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(P.big_recs), nbig, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0,
                            iy0, fix0, fiy0, P, st, qbit0, tid, lane);
 
     STAMP(3);
+    if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
 #pragma unroll 1
     for (int b = 0; b < 4; b++) {
@@ -917,8 +972,13 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : 5))
         const bool inb = px < P.width && py < P.height;
         uint32_t izk, iidk, zorig;
         init_key(P, px, py, inb, izk, iidk, zorig);
-        const uint32_t zkb = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
-        const uint32_t idb = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
+        const uint32_t zkr = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
+        const uint32_t idr = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
+        // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
+        const unsigned long long kreg = ((unsigned long long)zkr << 32) | idr;
+        const unsigned long long klds = TP ? lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK] : ~0ull;
+        const unsigned long long kmin = klds < kreg ? klds : kreg;
+        const uint32_t zkb = (uint32_t)(kmin >> 32), idb = (uint32_t)kmin;
         const bool none = !inb || ((zkb == izk) && (idb == iidk));
         const size_t pix = (size_t)py * P.width + px;
         const uint32_t prim = none ? NO_PRIM : (P.idflip ? (MAX_PRIM_ID - idb) : idb);
@@ -973,12 +1033,12 @@ hipError_t launch_geometry(const PassParams& P, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int KEYED>
+template <int KEYED, int TP>
 static void launch_raster_k(const PassParams& P, uint32_t programs, dim3 grid, hipStream_t stream) {
     const dim3 block(RASTER_THREADS);
-    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED>), grid, block, 0, stream, P);
-    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((raster_kernel<1, KEYED>), grid, block, 0, stream, P);
+    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P);
+    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((raster_kernel<1, KEYED, TP>), grid, block, 0, stream, P);
 }
 
 hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t stream) {
@@ -986,8 +1046,9 @@ hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t str
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
     const dim3 grid(P.tiles_x * rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
-    if (P.zflip == 0u && P.zmask == 0xFFFFFFFFu) launch_raster_k<0>(P, programs, grid, stream);
-    else launch_raster_k<1>(P, programs, grid, stream);
+    const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
+    if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(P, programs, grid, stream); else launch_raster_k<1, 1>(P, programs, grid, stream); }
+    else { if (plain) launch_raster_k<0, 0>(P, programs, grid, stream); else launch_raster_k<1, 0>(P, programs, grid, stream); }
     return hipGetLastError();
 }
 
