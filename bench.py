@@ -113,6 +113,20 @@ def tile_split_measurement(m, multigpu, torch, dist, dev0, rank, world, local_ra
             "steps": steps, "scaling": "strong", "n_gpus": world}
 
 
+def measured_traffic(workload: str):
+    """HBM bytes per raster_kernel launch from the latest committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected
+    in separate runs and corrected as MI355X_MICROARCH.md prescribes; see profiles/README.md).  Counters cannot be read
+    from inside this process, so the figure is the one measured for the same kernel build and workload, or null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + workload + "_hbm_traffic.json"))):
+        try:
+            best = json.load(open(path))["raster_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
 def main():
     args = parse_args()
     import torch
@@ -244,7 +258,7 @@ def main():
                        "frames_per_step": 1, "frames_in_flight": nfif},
             "shaded_mpix_per_s": round(scene.width * scene.height * frames_total / dt / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if split else measured_traffic(args.workload),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": round(ras_us, 3),
                          "geometry_kernel_us": round(geo_us, 3),
                          "how": "hipEvent pairs on the submit stream around every launch; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
