@@ -1,0 +1,142 @@
+"""glTF 2.0 -> SoA meshes, mirroring `Model::load` of the reference (crates/resources/src/model.rs:111-270):
+
+* iterates `document.meshes()` and their primitives -- node transforms are NOT applied (model.rs:135-144)
+* POSITION is required; missing NORMAL -> +Y, TEXCOORD_0 -> (0,0), TANGENT -> (1,0,0,1); missing indices ->
+  sequential 0..n (model.rs:160-215)
+* materials: base colour factor, metallic, roughness, emissive; AO 1.0 (model.rs:273-309, material.rs:6-30)
+* images are not decoded (the reference discards them, model.rs:120)
+
+This is SURVEY.md section 8f rank 1 (the caller side of the hot path): it feeds `interleave()` ->
+`Vertex` 48 B streams (crates/rhi/src/vertex.rs:88-170) that the rasterizer consumes.
+"""
+from __future__ import annotations
+
+import base64
+import json
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+_COMPONENT = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}
+
+
+class ResourceError(RuntimeError):
+    """crates/resources/src/error.rs:6-40"""
+
+
+@dataclass
+class Material:   # crates/resources/src/material.rs:6-30
+    base_color: tuple = (1.0, 1.0, 1.0, 1.0)
+    metallic: float = 0.0
+    roughness: float = 0.5
+    ao: float = 1.0
+    emissive: tuple = (0.0, 0.0, 0.0, 0.0)
+
+
+@dataclass
+class Mesh:       # crates/resources/src/model.rs:31-44
+    positions: np.ndarray
+    normals: np.ndarray
+    tex_coords: np.ndarray
+    tangents: np.ndarray
+    indices: np.ndarray
+    material_index: Optional[int] = None
+
+    @property
+    def vertex_count(self) -> int:
+        return int(self.positions.shape[0])
+
+    @property
+    def triangle_count(self) -> int:
+        return int(self.indices.size // 3)
+
+    def interleave(self) -> np.ndarray:
+        """-> (n, 12) float32 = `Vertex` 48 B: position@0 normal@12 tex_coord@24 tangent@32."""
+        v = np.zeros((self.vertex_count, 12), dtype=np.float32)
+        v[:, 0:3], v[:, 3:6], v[:, 6:8], v[:, 8:12] = self.positions, self.normals, self.tex_coords, self.tangents
+        return v
+
+
+@dataclass
+class Model:
+    meshes: List[Mesh] = field(default_factory=list)
+    materials: List[Material] = field(default_factory=list)
+    aabb_min: np.ndarray = None
+    aabb_max: np.ndarray = None
+
+    @property
+    def total_vertices(self) -> int:
+        return sum(m.vertex_count for m in self.meshes)
+
+    @property
+    def total_triangles(self) -> int:
+        return sum(m.triangle_count for m in self.meshes)
+
+
+def _read_accessor(doc, buffers, index) -> np.ndarray:
+    acc = doc["accessors"][index]
+    dtype = np.dtype(_COMPONENT[acc["componentType"]])
+    ncomp = _NCOMP[acc["type"]]
+    count = acc["count"]
+    if "bufferView" not in acc:
+        return np.zeros((count, ncomp), dtype=dtype)
+    bv = doc["bufferViews"][acc["bufferView"]]
+    raw = buffers[bv["buffer"]]
+    start = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
+    elem = dtype.itemsize * ncomp
+    stride = bv.get("byteStride", 0) or elem
+    if stride == elem:
+        out = np.frombuffer(raw, dtype=dtype, count=count * ncomp, offset=start).reshape(count, ncomp)
+    else:
+        need = stride * (count - 1) + elem
+        view = np.frombuffer(raw, dtype=np.uint8, count=need, offset=start)
+        out = np.lib.stride_tricks.as_strided(view, shape=(count, elem), strides=(stride, 1)).copy().view(dtype).reshape(count, ncomp)
+    return np.array(out)
+
+
+def load(path: str) -> Model:
+    if not os.path.exists(path):
+        raise ResourceError(f"File not found: {path}")                      # model.rs:113-115
+    try:
+        doc = json.load(open(path))
+        base = os.path.dirname(os.path.abspath(path))
+        buffers = []
+        for b in doc.get("buffers", []):
+            uri = b.get("uri", "")
+            if uri.startswith("data:"):
+                buffers.append(base64.b64decode(uri.split(",", 1)[1]))
+            else:
+                buffers.append(open(os.path.join(base, uri), "rb").read())
+    except (OSError, ValueError, KeyError) as e:
+        raise ResourceError(f"Failed to load glTF {path}: {e}")
+    materials = []
+    for m in doc.get("materials", []):                                       # model.rs:273-309
+        pbr = m.get("pbrMetallicRoughness", {})
+        em = m.get("emissiveFactor", [0.0, 0.0, 0.0])
+        materials.append(Material(tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])), float(pbr.get("metallicFactor", 1.0)),
+                                  float(pbr.get("roughnessFactor", 1.0)), 1.0, (em[0], em[1], em[2], 1.0)))
+    model = Model(materials=materials, aabb_min=np.full(3, np.finfo(np.float32).max, dtype=np.float32),
+                  aabb_max=np.full(3, np.finfo(np.float32).min, dtype=np.float32))
+    for mesh in doc.get("meshes", []):
+        for prim in mesh.get("primitives", []):
+            attrs = prim.get("attributes", {})
+            if "POSITION" not in attrs:
+                raise ResourceError("No position data")                     # model.rs:150-153
+            pos = _read_accessor(doc, buffers, attrs["POSITION"]).astype(np.float32)
+            n = pos.shape[0]
+            if n == 0:
+                continue
+            nrm = _read_accessor(doc, buffers, attrs["NORMAL"]).astype(np.float32) if "NORMAL" in attrs else np.tile(np.float32([0, 1, 0]), (n, 1))
+            uv = _read_accessor(doc, buffers, attrs["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in attrs else np.zeros((n, 2), dtype=np.float32)
+            tan = _read_accessor(doc, buffers, attrs["TANGENT"]).astype(np.float32) if "TANGENT" in attrs else np.tile(np.float32([1, 0, 0, 1]), (n, 1))
+            idx = (_read_accessor(doc, buffers, prim["indices"]).reshape(-1).astype(np.uint32) if "indices" in prim
+                   else np.arange(n, dtype=np.uint32))
+            model.aabb_min = np.minimum(model.aabb_min, pos.min(axis=0))
+            model.aabb_max = np.maximum(model.aabb_max, pos.max(axis=0))
+            model.meshes.append(Mesh(pos, nrm, uv, tan, idx, prim.get("material")))
+    if not model.meshes:
+        raise ResourceError("No meshes found in glTF file")                  # model.rs:262-264
+    return model

@@ -9,6 +9,7 @@ shaders/hlsl/pixel/model_full.hlsl:34-41).  Nothing here touches a GPU or the or
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -608,6 +609,26 @@ def textured_quad_case(width: int = 160, height: int = 120) -> Scene:
                  spot_lights=spot_light((-1.0, 0.5, 2.5), 0.95, (0.3, -0.1, -1.0), 0.8, (1.0, 0.8, 0.6), 6.0),
                  albedo_map=albedo, normal_map=Texture(nm))
     return Scene("textured-quad", width, height, [d], clear_color=(0.0, 0.0, 0.0, 1.0))
+
+
+def gltf_model(path: str, width: int = 1920, height: int = 1080, program: int = PROGRAM_MODEL_FULL,
+               eye=(0.0, 0.0, 3.2), yaw: float = 0.4) -> Scene:
+    """A glTF asset through the reference's loader semantics (gltf.load) -> `Vertex` streams, lit like config 3:
+    1 point light, base colour 0.7, roughness 0.5, white 1x1 albedo / "no normal map" textures."""
+    from . import gltf
+    model = gltf.load(path)
+    view, proj, cam = default_camera(width, height, eye=eye)
+    obj = object_ubo(trs((1.0, 1.0, 1.0), quat_axis_angle((0.0, 1.0, 0.0), yaw), (0.0, 0.0, 0.0)))
+    draws = []
+    for mesh in model.meshes:
+        draws.append(DrawSpec(vertices=mesh.interleave(), stride=48, count=int(mesh.indices.size), indices=mesh.indices,
+                              program=program, cull_mode=CULL_NONE, front_face=FRONT_CCW, camera=cam, object=obj,
+                              light=light_ubo(direction=(0.0, -1.0, 0.0), intensity=0.0, num_point=1),
+                              material=material_ubo((0.7, 0.7, 0.7, 1.0), 0.0, 0.5, 1.0),
+                              point_lights=point_light((2.0, 2.0, 2.0), 10.0, (1.0, 1.0, 1.0), 5.0),
+                              albedo_map=WHITE_1X1, normal_map=WHITE_1X1))
+    return Scene(f"gltf-{os.path.basename(os.path.dirname(os.path.abspath(path)))}-{model.total_triangles}", width, height, draws,
+                 clear_color=(0.1, 0.1, 0.15, 1.0))
 
 
 SMALL_CASES = {
