@@ -1,0 +1,105 @@
+"""Differential fuzzing of the HIP path against the oracle: random pipeline state x random geometry, including
+triangles that cross the near plane / guard band, sub-pixel slivers, shared vertices through u16 / u32 indices,
+partial viewports and scissors, every supported depth compare op and cull mode.  Integer outputs must be bit-exact."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_scene(scenes, seed):
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(33, 300)), int(rng.integers(17, 220))
+    draws = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.integers(0, 3)
+        cull = int(rng.integers(0, 3))
+        front = int(rng.integers(0, 2))
+        cmp_ = [scenes.CMP_LESS, scenes.CMP_LESS_OR_EQUAL, scenes.CMP_GREATER, scenes.CMP_GREATER_OR_EQUAL][int(rng.integers(0, 4))]
+        if rng.random() < 0.3:
+            vp = (float(rng.integers(-20, 20)), float(rng.integers(-20, 20)), float(W + rng.integers(-30, 40)), float(H + rng.integers(-20, 30)),
+                  float(rng.uniform(0, 0.3)), float(rng.uniform(0.6, 1.0)))
+        else:
+            vp = None
+        sc = (int(rng.integers(0, W // 3)), int(rng.integers(0, H // 3)), int(rng.integers(W // 3, W)), int(rng.integers(H // 3, H))) if rng.random() < 0.3 else None
+        if kind == 0:      # clip-space triangles with wild extents, some behind the camera (w varies through z only for MODEL)
+            n = int(rng.integers(1, 200))
+            scale = 10 ** rng.uniform(-2.5, 1.0)
+            c = rng.uniform(-1.2, 1.2, (n, 1, 2))
+            p = c + rng.normal(0, scale, (n, 3, 2))
+            z = rng.uniform(-0.2, 1.2, (n, 3, 1)) if rng.random() < 0.5 else np.repeat(rng.uniform(0, 1, (n, 1, 1)), 3, axis=1)
+            col = rng.uniform(0, 1, (n, 3, 3))
+            verts = np.concatenate([p, z, col], axis=2).astype(np.float32).reshape(n * 3, 6)
+            d = scenes.DrawSpec(vertices=verts, stride=24, count=3 * n, program=scenes.PROGRAM_TRIANGLE)
+        else:              # indexed lit mesh through a perspective camera placed so that some triangles cross the near plane
+            nu, nv = int(rng.integers(2, 14)), int(rng.integers(2, 11))
+            s = scenes.displaced_sphere(nu, nv, W, H, seed=int(rng.integers(1, 1 << 30)),
+                                        program=scenes.PROGRAM_MODEL if kind == 1 else scenes.PROGRAM_MODEL_FULL).draws[0]
+            eye = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.0, 1.0)), float(rng.uniform(0.3, 4.0)))
+            view = scenes.look_at_rh(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+            proj = scenes.projection_vulkan(math.radians(float(rng.uniform(30, 100))), W / H, float(rng.uniform(0.05, 0.6)), float(rng.uniform(3, 50)))
+            s.camera = scenes.camera_ubo(view, proj, eye)
+            model = scenes.trs(tuple(rng.uniform(0.5, 1.5, 3)), scenes.quat_axis_angle(rng.normal(size=3), float(rng.uniform(0, 6))), tuple(rng.uniform(-0.5, 0.5, 3)))
+            s.object = scenes.object_ubo(model)
+            if rng.random() < 0.5:
+                s.indices = s.indices.astype(np.uint16)
+            if rng.random() < 0.4:   # draw a sub-range through first_index / vertex_offset
+                pad = int(rng.integers(1, 7))
+                s.vertices = np.concatenate([np.zeros((pad, 12), dtype=np.float32), s.vertices], axis=0)
+                s.vertex_offset = pad
+                s.first = 3 * int(rng.integers(0, s.count // 6))
+                s.count = 3 * int(rng.integers(1, (s.indices.size - s.first) // 3 + 1))
+            d = s
+        d.cull_mode, d.front_face, d.depth_compare, d.viewport, d.scissor = cull, front, cmp_, vp, sc
+        draws.append(d)
+    for d in draws:          # one rendering scope shares one depth state
+        d.depth_compare = draws[0].depth_compare
+    greater = draws[0].depth_compare in (scenes.CMP_GREATER, scenes.CMP_GREATER_OR_EQUAL)
+    return scenes.Scene(f"fuzz-{seed}", W, H, draws, clear_color=tuple(rng.uniform(0, 1, 3)) + (1.0,),
+                        clear_depth=float(rng.uniform(0.0, 0.4)) if greater else float(rng.uniform(0.6, 1.0)))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_against_oracle(mirhi, oracle, device, scenes, seed):
+    scene = _random_scene(scenes, 1000 + seed)
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    diff = out["prim"] != ref["prim"]
+    assert not diff.any(), f"{scene.name}: {int(diff.sum())} pixels differ in winning primitive (first {np.argwhere(diff)[0]})"
+    cov = ref["prim"] != 0xFFFFFFFF
+    assert np.array_equal(out["depth"].view(np.uint32)[cov], ref["depth"].view(np.uint32)[cov]), f"{scene.name}: depth bits differ"
+    a, b = out["color"], ref["rgba"]
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan)
+    err = np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b)))
+    assert err.max() < 1e-4, f"{scene.name}: max |dRGBA| {err.max()}"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hostile_vertex_values(mirhi, oracle, device, scenes, seed):
+    """NaN / Inf / huge / denormal coordinates and colours: no hang, no fault, and the same pixels as the oracle."""
+    rng = np.random.default_rng(77 + seed)
+    n = 300
+    verts = scenes.random_triangles(n, 200, 150, seed=500 + seed, rmin=2, rmax=60).draws[0].vertices.copy()
+    specials = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 1e-42, -0.0, 3.4e38], dtype=np.float32)
+    for _ in range(120):
+        verts[int(rng.integers(0, 3 * n)), int(rng.integers(0, 6))] = specials[int(rng.integers(0, len(specials)))]
+    d = scenes.DrawSpec(vertices=verts, stride=24, count=3 * n, cull_mode=scenes.CULL_NONE)
+    scene = scenes.Scene(f"hostile-{seed}", 200, 150, [d])
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    f = mirhi.Fence(device)
+    res.render(f)
+    f.wait(5_000_000_000)
+    out = res.read()
+    res.destroy()
+    f.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"])
+    cov = ref["prim"] != 0xFFFFFFFF
+    assert np.array_equal(out["depth"].view(np.uint32)[cov], ref["depth"].view(np.uint32)[cov])
+    assert np.array_equal(np.isnan(out["color"]), np.isnan(ref["rgba"]))
