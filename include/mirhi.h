@@ -121,7 +121,8 @@ typedef enum {   /* replaces Shader::from_spirv_file (shader.rs:244-330): precom
     MIRHI_PROGRAM_NONE = -1,
     MIRHI_PROGRAM_TRIANGLE = 0,     /* vertex/triangle.hlsl + pixel/triangle.hlsl */
     MIRHI_PROGRAM_MODEL = 1,        /* vertex/model.hlsl + pixel/model.hlsl (hard-coded fallback light/material) */
-    MIRHI_PROGRAM_MODEL_FULL = 2    /* vertex/model.hlsl + pixel/model_full.hlsl + lights.hlsli */
+    MIRHI_PROGRAM_MODEL_FULL = 2,   /* vertex/model.hlsl + pixel/model_full.hlsl + lights.hlsli */
+    MIRHI_PROGRAM_MODEL_PBR = 3     /* vertex/model.hlsl + pixel/model_pbr.hlsl + pbr.hlsli (Cook-Torrance GGX; no shadow pass: shadow = 1) */
 } mirhi_program;
 typedef enum { MIRHI_TOPOLOGY_POINT_LIST = 0, MIRHI_TOPOLOGY_LINE_LIST = 1, MIRHI_TOPOLOGY_LINE_STRIP = 2,
                MIRHI_TOPOLOGY_TRIANGLE_LIST = 3, MIRHI_TOPOLOGY_TRIANGLE_STRIP = 4, MIRHI_TOPOLOGY_TRIANGLE_FAN = 5 } mirhi_topology;   /* pipeline.rs:274-300 */
@@ -185,12 +186,14 @@ typedef enum {
     MIRHI_SLOT_CAMERA = 0,        /* b0 CameraData 208 B */
     MIRHI_SLOT_OBJECT = 1,        /* b1 ObjectData 128 B */
     MIRHI_SLOT_LIGHTS = 2,        /* b2 LightUBO 48 B */
-    MIRHI_SLOT_MATERIAL = 3,      /* b3 MaterialData 32 B */
+    MIRHI_SLOT_MATERIAL = 3,      /* b3 MaterialData 32 B (model_full.hlsl:34-41); 80 B for MODEL_PBR (model_pbr.hlsl:36-59) */
     MIRHI_SLOT_POINT_LIGHTS = 4,  /* t0,space1 StructuredBuffer<PointLight> */
     MIRHI_SLOT_SPOT_LIGHTS = 5,   /* t1,space1 StructuredBuffer<SpotLight> */
     MIRHI_SLOT_COUNT = 6
 } mirhi_uniform_slot;
-typedef enum { MIRHI_TEXTURE_ALBEDO = 0 /* t0 */, MIRHI_TEXTURE_NORMAL = 1 /* t1 */, MIRHI_TEXTURE_COUNT = 2 } mirhi_texture_slot;
+typedef enum { MIRHI_TEXTURE_ALBEDO = 0 /* t0 */, MIRHI_TEXTURE_NORMAL = 1 /* t1 */,
+               MIRHI_TEXTURE_METALLIC_ROUGHNESS = 2 /* t2 */, MIRHI_TEXTURE_OCCLUSION = 3 /* t3 */, MIRHI_TEXTURE_EMISSIVE = 4 /* t4 (model_pbr.hlsl:62-95) */,
+               MIRHI_TEXTURE_COUNT = 5 } mirhi_texture_slot;
 
 mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out);                 /* CommandPool::new + CommandBuffer::new :89,:297 */
 mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd);

@@ -359,6 +359,7 @@ static int depth_cmp(uint32_t op, float z, float stored) {
  * a8: fragment shading of one visible pixel
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { v3 world, normal, tangent, bitangent; float u, v; v3 color; } varyings;
+static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, float rgba[4]);
 
 static void vs_varyings(const oracle_draw* d, uint32_t vidx, v4* clip, varyings* o) {
     const uint8_t* vtx = d->vertex_data + (size_t)vidx * d->vertex_stride;
@@ -435,6 +436,7 @@ static void shade_pixel(const oracle_pass* pass, const oracle_draw* d, uint32_t 
         rgba[0] = col.x; rgba[1] = col.y; rgba[2] = col.z; rgba[3] = 1.0f;
         return;
     }
+    if (d->program == ORACLE_PROGRAM_MODEL_PBR) { shade_pbr(d, b, vv, worldPos, Nv, V, rgba); return; }
     /* ORACLE_PROGRAM_MODEL_FULL: pixel/model_full.hlsl:85-150 */
     float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
@@ -500,8 +502,133 @@ static void shade_pixel(const oracle_pass* pass, const oracle_draw* d, uint32_t 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * a8: Cook-Torrance GGX, shaders/hlsl/pbr.hlsli + pixel/model_pbr.hlsl (no shadow pass: shadow = 1)
+ * ---------------------------------------------------------------------------------------------- */
+#define PBR_PI 3.14159265358979323846f
+#define PBR_EPSILON 0.0001f
+static float max0(float x) { return x > 0.0f ? x : 0.0f; }                /* max(x, 0.0); NaN -> 0 */
+float oracle_distribution_ggx(float NdotH, float roughness) {              /* pbr.hlsli:55-69 (NdotH already max(.,0)) */
+    float a = roughness * roughness, a2 = a * a;
+    float NdotH2 = NdotH * NdotH;
+    float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+    denom = (PBR_PI * denom) * denom;
+    return a2 / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+float oracle_geometry_schlick_ggx(float NdotV, float roughness) {          /* pbr.hlsli:83-93 */
+    float r = roughness + 1.0f;
+    float k = (r * r) / 8.0f;
+    float denom = NdotV * (1.0f - k) + k;
+    return NdotV / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+typedef struct { v3 albedo; float metallic, roughness, ao; v3 emissive; } pbr_material;
+static v3 pbr_direct(v3 N, v3 V, v3 L, v3 radiance, const pbr_material* m) {   /* CalculatePBRDirect pbr.hlsli:292-333 */
+    v3 H = normalize3(add3(V, L));
+    v3 F0 = {0.04f + (m->albedo.x - 0.04f) * m->metallic, 0.04f + (m->albedo.y - 0.04f) * m->metallic,
+             0.04f + (m->albedo.z - 0.04f) * m->metallic};
+    float NDF = oracle_distribution_ggx(max0(dot3(N, H)), m->roughness);
+    float NdotV = max0(dot3(N, V)), NdotL = max0(dot3(N, L));
+    float G = oracle_geometry_schlick_ggx(NdotV, m->roughness) * oracle_geometry_schlick_ggx(NdotL, m->roughness);
+    float ct = saturatef(max0(dot3(H, V)));
+    float p5 = powf(1.0f - ct, 5.0f);                                       /* FresnelSchlick :131-136 */
+    v3 F = {F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5};
+    float om = 1.0f - m->metallic;
+    v3 kD = {(1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om};
+    float ndg = NDF * G;
+    float denominator = (4.0f * NdotV) * NdotL + PBR_EPSILON;
+    v3 specular = {(ndg * F.x) / denominator, (ndg * F.y) / denominator, (ndg * F.z) / denominator};
+    v3 r;
+    r.x = (((kD.x * m->albedo.x) / PBR_PI + specular.x) * radiance.x) * NdotL;
+    r.y = (((kD.y * m->albedo.y) / PBR_PI + specular.y) * radiance.y) * NdotL;
+    r.z = (((kD.z * m->albedo.z) / PBR_PI + specular.z) * radiance.z) * NdotL;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * raster + resolve + shade of one row band
  * ---------------------------------------------------------------------------------------------- */
+
+static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, float rgba[4]) {
+    /* pixel/model_pbr.hlsl:159-320; MaterialData :36-59 (80 B) */
+    const varyings* vv = (const varyings*)vvp;
+    const void* M = d->material;
+    float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
+    float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+    v4 baseColor = {rdf(M, 0), rdf(M, 4), rdf(M, 8), rdf(M, 12)};
+    float metallic = rdf(M, 16), roughness = rdf(M, 20), ao = rdf(M, 24), normalScale = rdf(M, 28);
+    v3 emissive = {rdf(M, 32), rdf(M, 36), rdf(M, 40)};
+    uint32_t hasBase = rdu(M, 48), hasNormal = rdu(M, 52), hasMR = rdu(M, 56), hasOcc = rdu(M, 60), hasEm = rdu(M, 64);
+    if (hasBase) {
+        v4 t = sample_bilinear(&d->albedo_map, u, v);
+        baseColor.x = t.x * baseColor.x; baseColor.y = t.y * baseColor.y; baseColor.z = t.z * baseColor.z; baseColor.w = t.w * baseColor.w;
+    }
+    if (hasMR) { v4 t = sample_bilinear(&d->metallic_roughness_map, u, v); roughness = roughness * t.y; metallic = metallic * t.z; }
+    if (hasOcc) { v4 t = sample_bilinear(&d->occlusion_map, u, v); ao = ao * t.x; }
+    if (hasEm) { v4 t = sample_bilinear(&d->emissive_map, u, v); emissive.x *= t.x; emissive.y *= t.y; emissive.z *= t.z; }
+    v3 N = normalize3(Nv);                                                  /* GetWorldNormal :124-151 */
+    if (hasNormal) {
+        v4 nc = sample_bilinear(&d->normal_map, u, v);
+        v3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
+        if (!(length3(ncm1) < 0.01f)) {
+            v3 ns = {(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f};
+            ns = normalize3(ns);
+            v3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
+            v3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+            N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
+        }
+    }
+    pbr_material m;
+    m.albedo.x = baseColor.x; m.albedo.y = baseColor.y; m.albedo.z = baseColor.z;
+    m.metallic = metallic; m.roughness = roughness > 0.04f ? roughness : 0.04f;   /* ClampRoughness :476-479 */
+    m.ao = ao; m.emissive = emissive;
+    v3 lighting = {0.0f, 0.0f, 0.0f};
+    {
+        v3 dir = {rdf(d->light_ubo, 0), rdf(d->light_ubo, 4), rdf(d->light_ubo, 8)};
+        float intensity = rdf(d->light_ubo, 12);
+        v3 color = {rdf(d->light_ubo, 16), rdf(d->light_ubo, 20), rdf(d->light_ubo, 24)};
+        v3 nd = {-dir.x, -dir.y, -dir.z};
+        lighting = add3(lighting, pbr_direct(N, V, normalize3(nd), scale3(color, intensity), &m));   /* shadow = 1 */
+    }
+    uint32_t numPoint = d->point_lights ? rdu(d->light_ubo, 32) : 0, numSpot = d->spot_lights ? rdu(d->light_ubo, 36) : 0;
+    for (uint32_t i = 0; i < numPoint; i++) {
+        const uint8_t* L = (const uint8_t*)d->point_lights + 32u * i;
+        v3 pos = {rdf(L, 0), rdf(L, 4), rdf(L, 8)};
+        float radius = rdf(L, 12);
+        v3 color = {rdf(L, 16), rdf(L, 20), rdf(L, 24)};
+        float intensity = rdf(L, 28);
+        v3 lightVec = sub3(pos, worldPos);
+        float dist = length3(lightVec);
+        v3 Ld = scale3(lightVec, 1.0f / dist);
+        v3 radiance = scale3(scale3(color, intensity), oracle_attenuation(dist, radius));
+        lighting = add3(lighting, pbr_direct(N, V, Ld, radiance, &m));
+    }
+    for (uint32_t j = 0; j < numSpot; j++) {
+        const uint8_t* L = (const uint8_t*)d->spot_lights + 48u * j;
+        v3 pos = {rdf(L, 0), rdf(L, 4), rdf(L, 8)};
+        float innerCos = rdf(L, 12);
+        v3 sdir = {rdf(L, 16), rdf(L, 20), rdf(L, 24)};
+        float outerCos = rdf(L, 28);
+        v3 color = {rdf(L, 32), rdf(L, 36), rdf(L, 40)};
+        float intensity = rdf(L, 44);
+        v3 lightVec = sub3(pos, worldPos);
+        float dist = length3(lightVec);
+        v3 Ld = scale3(lightVec, 1.0f / dist);
+        float datt = oracle_attenuation(dist, 50.0f);
+        float satt = spot_attenuation(Ld, normalize3(sdir), innerCos, outerCos);
+        v3 radiance = scale3(scale3(scale3(color, intensity), datt), satt);
+        lighting = add3(lighting, pbr_direct(N, V, Ld, radiance, &m));
+    }
+    /* CalculateHemisphereAmbient pbr.hlsli:483-492 */
+    float up = N.y * 0.5f + 0.5f;
+    v3 sky = {0.15f, 0.18f, 0.25f}, ground = {0.08f, 0.06f, 0.04f};
+    v3 amb = {ground.x + (sky.x - ground.x) * up, ground.y + (sky.y - ground.y) * up, ground.z + (sky.z - ground.z) * up};
+    float om = 1.0f - m.metallic;
+    v3 ambient = scale3(scale3(mul3(amb, m.albedo), m.ao), om);
+    float aol = 1.0f + (m.ao - 1.0f) * 0.5f;                                 /* lerp(1, ao, 0.5) :311 */
+    lighting = scale3(lighting, aol);
+    v3 col = add3(add3(ambient, lighting), m.emissive);
+    rgba[0] = col.x; rgba[1] = col.y; rgba[2] = col.z; rgba[3] = baseColor.w;
+}
+
 typedef struct {
     const oracle_pass* pass;
     const tri_list* tris;
@@ -578,7 +705,19 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
         const oracle_draw* d = &pass->draws[di];
         prim_base[di] = base;
         uint32_t ntri = d->count / 3u;                            /* TriangleList (pipeline.rs:655) */
-        for (uint32_t t = 0; t < ntri; t++) {
+        int dropped = 0;
+        if (d->program == ORACLE_PROGRAM_MODEL_PBR) {
+            /* pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` -- restated where one decision
+             * covers the whole draw: alpha = baseColorFactor.a, or texel alpha in [0,1] times it.  A draw whose
+             * texels could fall on both sides of the cutoff needs a per-fragment discard before the depth write;
+             * that is outside this restatement (and the HIP path): report it instead of rendering it wrong. */
+            float fa = rdf(d->material, 12), cutoff = rdf(d->material, 44);
+            float lo = fa, hi = fa;
+            if (rdu(d->material, 48) != 0) { lo = fa < 0.0f ? fa : 0.0f; hi = fa > 0.0f ? fa : 0.0f; }
+            if (hi < cutoff) dropped = 1;
+            else if (!(lo >= cutoff)) { free(prim_base); free(tris.v); return 2; }
+        }
+        for (uint32_t t = 0; t < ntri && !dropped; t++) {
             v4 c[3];
             for (uint32_t k = 0; k < 3; k++) c[k] = vs_position(d, fetch_index(d, 3u * t + k), NULL);
             process_triangle(pass, d, di, base + t, c, &tris);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-enum { ORACLE_PROGRAM_TRIANGLE = 0, ORACLE_PROGRAM_MODEL = 1, ORACLE_PROGRAM_MODEL_FULL = 2 };
+enum { ORACLE_PROGRAM_TRIANGLE = 0, ORACLE_PROGRAM_MODEL = 1, ORACLE_PROGRAM_MODEL_FULL = 2, ORACLE_PROGRAM_MODEL_PBR = 3 };
 enum { ORACLE_CULL_NONE = 0, ORACLE_CULL_FRONT = 1, ORACLE_CULL_BACK = 2, ORACLE_CULL_FRONT_AND_BACK = 3 };
 enum { ORACLE_FRONT_CCW = 0, ORACLE_FRONT_CW = 1 };
 /* crates/rhi/src/pipeline.rs:375-409 CompareOp order */
@@ -70,6 +70,8 @@ typedef struct {
     const void* point_lights;   /* PointLight[NumPointLights], 32 B each */
     const void* spot_lights;    /* SpotLight[NumSpotLights], 48 B each */
     oracle_texture albedo_map, normal_map;
+    /* MODEL_PBR only (pixel/model_pbr.hlsl:62-95): t2 metallic-roughness, t3 occlusion, t4 emissive; material is the 80 B block :36-59 */
+    oracle_texture metallic_roughness_map, occlusion_map, emissive_map;
 } oracle_draw;
 
 typedef struct {
@@ -101,6 +103,10 @@ float oracle_attenuation(float distance, float radius);       /* lights.hlsli:63
 float oracle_roughness_to_shininess(float roughness);         /* lights.hlsli:152-159 */
 void  oracle_blinn_phong(const float L[3], const float V[3], const float N[3], const float light_color[3],
                          const float albedo[3], float shininess, float out[3]); /* lights.hlsli:95-117 */
+
+/* pbr.hlsli helpers exposed for known-answer tests */
+float oracle_distribution_ggx(float n_dot_h, float roughness);   /* pbr.hlsli:55-69 */
+float oracle_geometry_schlick_ggx(float n_dot_v, float roughness); /* pbr.hlsli:83-93 */
 
 /* glam 0.30.9 restatements (column-major float[16]); call sites cited in SURVEY 8c */
 void oracle_glam_perspective_rh(float fovy, float aspect, float z_near, float z_far, float out[16]);

@@ -37,7 +37,7 @@ class Format:
 
 
 class Program:
-    NONE, TRIANGLE, MODEL, MODEL_FULL = -1, 0, 1, 2
+    NONE, TRIANGLE, MODEL, MODEL_FULL, MODEL_PBR = -1, 0, 1, 2, 3
 
 
 class PrimitiveTopology:  # pipeline.rs:274-282
@@ -77,7 +77,7 @@ class Slot:
 
 
 class TextureSlot:
-    ALBEDO, NORMAL = range(2)
+    ALBEDO, NORMAL, METALLIC_ROUGHNESS, OCCLUSION, EMISSIVE = range(5)
 
 
 class Kernel:
@@ -633,7 +633,7 @@ class SceneResources:
                       material=buf(BufferUsage.Uniform, d.material, key=("u", d.material)),
                       point=buf(BufferUsage.Storage if False else BufferUsage.Uniform, d.point_lights or None, key=("u", d.point_lights)),
                       spot=buf(BufferUsage.Uniform, d.spot_lights or None, key=("u", d.spot_lights)),
-                      albedo=tex(d.albedo_map), normal=tex(d.normal_map), draw=d)
+                      textures=[tex(t) for t in d.textures], draw=d)
             self.draw_state.append(st)
         self.record()
 
@@ -654,8 +654,9 @@ class SceneResources:
                               (Slot.MATERIAL, "material"), (Slot.POINT_LIGHTS, "point"), (Slot.SPOT_LIGHTS, "spot")):
                 if st[key] is not None:
                     cmd.bind_uniform(slot, st[key])
-            cmd.bind_texture(TextureSlot.ALBEDO, st["albedo"])
-            cmd.bind_texture(TextureSlot.NORMAL, st["normal"])
+            for slot, img in enumerate(st["textures"]):
+                if img is not None or slot < 2:
+                    cmd.bind_texture(slot, img)
             if st["ib"] is not None:
                 cmd.bind_index_buffer(st["ib"], 0, IndexType.UINT16 if d.index_type == 2 else IndexType.UINT32)
                 cmd.draw_indexed(d.count, 1, d.first, d.vertex_offset, 0)

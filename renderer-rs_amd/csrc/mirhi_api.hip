@@ -158,7 +158,7 @@ struct mirhi_cmd {
     mirhi_buffer* vb = nullptr; uint64_t vb_offset = 0;
     mirhi_buffer* ib = nullptr; uint64_t ib_offset = 0; mirhi_index_type ib_type = MIRHI_INDEX_UINT32;
     struct { mirhi_buffer* buf; uint64_t offset, range; } uniforms[MIRHI_SLOT_COUNT] = {};
-    mirhi_image* textures[MIRHI_TEXTURE_COUNT] = {nullptr, nullptr};
+    mirhi_image* textures[MIRHI_TEXTURE_COUNT] = {};
     bool has_viewport = false, has_scissor = false;
     mirhi_viewport viewport{};
     mirhi_rect2d scissor{};
@@ -479,7 +479,7 @@ extern "C" mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pip
     if (d->blend_attachment_count != 0 && d->blend_attachment_count != d->color_attachment_count)
         return fail(MIRHI_ERR_PIPELINE, "Pipeline error: Blend attachment count (%u) must match color attachment count (%u)", d->blend_attachment_count, d->color_attachment_count);
     // --- program selection replaces SPIR-V module creation (shader.rs:244-330) ---
-    if (d->vertex_program < 0 || d->vertex_program > MIRHI_PROGRAM_MODEL_FULL || d->fragment_program < 0 || d->fragment_program > MIRHI_PROGRAM_MODEL_FULL)
+    if (d->vertex_program < 0 || d->vertex_program > MIRHI_PROGRAM_MODEL_PBR || d->fragment_program < 0 || d->fragment_program > MIRHI_PROGRAM_MODEL_PBR)
         return fail(MIRHI_ERR_SHADER, "Shader error: unknown program id (vertex %d, fragment %d)", d->vertex_program, d->fragment_program);
     const bool vs_model = d->vertex_program != MIRHI_PROGRAM_TRIANGLE, fs_model = d->fragment_program != MIRHI_PROGRAM_TRIANGLE;
     if (vs_model != fs_model)
@@ -572,7 +572,7 @@ static void reset_recording(mirhi_cmd* c) {
     c->in_rendering = false;
     c->pipeline = nullptr; c->vb = nullptr; c->ib = nullptr;
     for (auto& u : c->uniforms) u = {nullptr, 0, 0};
-    c->textures[0] = c->textures[1] = nullptr;
+    for (auto& tx : c->textures) tx = nullptr;
     c->has_viewport = c->has_scissor = false;
 }
 static mirhi_result begin_common(mirhi_cmd* cmd, bool one_time) {
@@ -748,12 +748,12 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
         d.camera = (const float*)p;
         if ((r = uptr(MIRHI_SLOT_OBJECT, 128, &p, "ObjectData (b1)")) != MIRHI_OK) return r;
         d.object = (const float*)p;
-        if (d.program == MIRHI_PROGRAM_MODEL_FULL) {
+        if (d.program == MIRHI_PROGRAM_MODEL_FULL || d.program == MIRHI_PROGRAM_MODEL_PBR) {
             if ((r = uptr(MIRHI_SLOT_LIGHTS, 48, &d.lights, "LightUBO (b2)")) != MIRHI_OK) return r;
-            if ((r = uptr(MIRHI_SLOT_MATERIAL, 32, &d.material, "MaterialData (b3)")) != MIRHI_OK) return r;
+            if ((r = uptr(MIRHI_SLOT_MATERIAL, d.program == MIRHI_PROGRAM_MODEL_PBR ? 80 : 32, &d.material, "MaterialData (b3)")) != MIRHI_OK) return r;
             if (cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf) d.point_lights = cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].offset;
             if (cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf) d.spot_lights = cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].offset;
-            for (int t = 0; t < 2; t++)
+            for (int t = 0; t < (d.program == MIRHI_PROGRAM_MODEL_PBR ? 5 : 2); t++)
                 if (cmd->textures[t]) { d.tex[t] = cmd->textures[t]->ptr; d.tex_w[t] = cmd->textures[t]->width; d.tex_h[t] = cmd->textures[t]->height; }
         }
     }
@@ -876,7 +876,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             DrawDesc& dd = pass.draws[di];
             dd.vs_words = 0; dd.vs_out = nullptr;
             if (dd.program == MIRHI_PROGRAM_TRIANGLE) continue;
-            const uint32_t words = dd.program == MIRHI_PROGRAM_MODEL_FULL ? 5u : 3u;
+            const uint32_t words = dd.program == MIRHI_PROGRAM_MODEL ? 3u : 5u;
             const uint64_t vbb = pass.draw_vb_bytes[di];
             const uint32_t count = vbb >= 48 ? (uint32_t)((vbb - 48) / dd.stride + 1) : 0u;
             size_t found = SIZE_MAX;
@@ -973,7 +973,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         all.insert(all.end(), pass.draws.begin(), pass.draws.end());
         cmd->plan.push_back(P);
         uint32_t progs = 0;
-        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : 2u;
+        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : (dd.program == MIRHI_PROGRAM_MODEL_PBR ? 4u : 2u);
         cmd->plan_programs.push_back(progs ? progs : 1u);
         cmd->plan_tris += pass.total_tris;
     }
@@ -1068,6 +1068,8 @@ static mirhi_result fence_complete(mirhi_fence* f) {
         if (c->ws.status_host) {
             f->dev->stats.last_status = c->ws.status_host[0];
             f->dev->stats.last_big_list = c->ws.status_host[1];
+            if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
+                r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: MODEL_PBR alpha cutoff together with a base colour texture (per-fragment discard); that draw was skipped");
             if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)
                 r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer large-triangle list overflowed (%u entries); frame is incomplete", c->ws.status_host[1]);
         }

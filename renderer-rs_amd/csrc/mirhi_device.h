@@ -24,7 +24,7 @@ constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay in
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t MAX_PRIM_ID = 0xFFFFFFFDu;
 
-enum : uint32_t { STATUS_BIG_OVERFLOW = 1u };
+enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u };
 
 struct DrawDesc {
     const uint8_t* vb;            // binding 0 base + bind offset
@@ -35,8 +35,8 @@ struct DrawDesc {
     const uint8_t* material;      // b3 MaterialData
     const uint8_t* point_lights;  // t0 space1
     const uint8_t* spot_lights;   // t1 space1
-    const uint8_t* tex[2];        // t0 albedo, t1 normal (RGBA8)
-    uint32_t tex_w[2], tex_h[2];
+    const uint8_t* tex[5];        // t0 albedo, t1 normal, t2 metallic-roughness, t3 occlusion, t4 emissive (RGBA8)
+    uint32_t tex_w[5], tex_h[5];
     uint32_t stride;
     uint32_t index_type;          // 0 none, 2 u16, 4 u32
     uint32_t first;               // first_vertex / first_index
@@ -52,8 +52,8 @@ struct DrawDesc {
     int32_t  sx0, sy0, sx1, sy1;  // inclusive scissor (already clamped to render area and extent)
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
     uint32_t vs_words;            // 16-byte words per shaded vertex (3 MODEL, 5 MODEL_FULL, 0 = no vertex pre-pass)
+    uint32_t pad[2];
     const void* vs_out;           // shaded vertices of this draw's vertex buffer (see VsJob), indexed like the vertex buffer
-    uint64_t pad2;
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");
 

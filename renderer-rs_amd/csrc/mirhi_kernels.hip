@@ -379,7 +379,22 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
     uint32_t any = 0;
     ScreenTri t;
     f4 c[3];
-    if (tri < D.tri_count) {
+    bool dropped = false;
+    if (D.program == 3) {
+        // pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` decided per draw: alpha is
+        // baseColorFactor.a, or a texel alpha in [0,1] times it.  A draw whose texels could fall on both sides of
+        // the cutoff would need a per-fragment discard before the depth write: reported, not rendered.
+        const CBytePtr M = cb(D.material);
+        const float fa = ldcf(M, 12), cutoff = ldcf(M, 44);
+        float lo = fa, hi = fa;
+        if (ldcu(M, 48) != 0u) { lo = fa < 0.0f ? fa : 0.0f; hi = fa > 0.0f ? fa : 0.0f; }
+        if (hi < cutoff) dropped = true;
+        else if (!(lo >= cutoff)) {
+            dropped = true;
+            if (threadIdx.x == 0) __hip_atomic_fetch_or(P.status, STATUS_ALPHA_TEST_TEXTURED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (tri < D.tri_count && !dropped) {
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t vidx = fetch_index(D, 3u * tri + k);
@@ -537,9 +552,130 @@ __device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, fl
 }
 #pragma clang fp contract(off)
 
+// a8: Cook-Torrance GGX, shaders/hlsl/pbr.hlsli (shadow pass not on the path: shadow = 1)
+#define PBR_PI 3.14159265358979323846f
+#define PBR_EPSILON 0.0001f
+__device__ __forceinline__ float max0(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __forceinline__ float distribution_ggx(float NdotH, float roughness) {       // pbr.hlsli:55-69
+    const float a = roughness * roughness, a2 = a * a;
+    const float NdotH2 = NdotH * NdotH;
+    float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+    denom = (PBR_PI * denom) * denom;
+    return a2 / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+__device__ __forceinline__ float geometry_schlick_ggx(float NdotV, float roughness) {   // pbr.hlsli:83-93
+    const float r = roughness + 1.0f;
+    const float k = (r * r) / 8.0f;
+    const float denom = NdotV * (1.0f - k) + k;
+    return NdotV / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+struct PbrMaterial { f3 albedo; float metallic, roughness; };
+__device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const PbrMaterial& m) {   // pbr.hlsli:292-333
+    const f3 H = normalize3(add3(V, L));
+    const f3 F0 = {0.04f + (m.albedo.x - 0.04f) * m.metallic, 0.04f + (m.albedo.y - 0.04f) * m.metallic,
+                   0.04f + (m.albedo.z - 0.04f) * m.metallic};
+    const float NDF = distribution_ggx(max0(dot3(N, H)), m.roughness);
+    const float NdotV = max0(dot3(N, V)), NdotL = max0(dot3(N, L));
+    const float G = geometry_schlick_ggx(NdotV, m.roughness) * geometry_schlick_ggx(NdotL, m.roughness);
+    const float ct = saturatef(max0(dot3(H, V)));
+    const float p5 = fpow(1.0f - ct, 5.0f);                                             // FresnelSchlick :131-136
+    const f3 F = {F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5};
+    const float om = 1.0f - m.metallic;
+    const f3 kD = {(1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om};
+    const float ndg = NDF * G;
+    const float denominator = (4.0f * NdotV) * NdotL + PBR_EPSILON;
+    const f3 specular = {(ndg * F.x) / denominator, (ndg * F.y) / denominator, (ndg * F.z) / denominator};
+    return {(((kD.x * m.albedo.x) / PBR_PI + specular.x) * radiance.x) * NdotL,
+            (((kD.y * m.albedo.y) / PBR_PI + specular.y) * radiance.y) * NdotL,
+            (((kD.z * m.albedo.z) / PBR_PI + specular.z) * radiance.z) * NdotL};
+}
+
+// pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
+__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyings vv[3], f3 worldPos, f3 V, f3 N) {
+    const CBytePtr M = cb(D.material);                                                  // MaterialData :36-59 (80 B)
+    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
+    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+    f4 baseColor = {ldcf(M, 0), ldcf(M, 4), ldcf(M, 8), ldcf(M, 12)};
+    float metallic = ldcf(M, 16), roughness = ldcf(M, 20), ao = ldcf(M, 24);
+    const float normalScale = ldcf(M, 28);
+    f3 emissive = {ldcf(M, 32), ldcf(M, 36), ldcf(M, 40)};
+    if (ldcu(M, 48) != 0u) {
+        const f4 t = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+        baseColor = {t.x * baseColor.x, t.y * baseColor.y, t.z * baseColor.z, t.w * baseColor.w};
+    }
+    if (ldcu(M, 56) != 0u) {
+        const f4 t = sample_bilinear(D.tex[2], D.tex_w[2], D.tex_h[2], u, v);
+        roughness = roughness * t.y; metallic = metallic * t.z;
+    }
+    if (ldcu(M, 60) != 0u) ao = ao * sample_bilinear(D.tex[3], D.tex_w[3], D.tex_h[3], u, v).x;
+    if (ldcu(M, 64) != 0u) {
+        const f4 t = sample_bilinear(D.tex[4], D.tex_w[4], D.tex_h[4], u, v);
+        emissive = {emissive.x * t.x, emissive.y * t.y, emissive.z * t.z};
+    }
+    if (ldcu(M, 52) != 0u) {                                                            // GetWorldNormal :124-151
+        const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+        const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
+        if (!(length3(ncm1) < 0.01f)) {
+            const f3 ns = normalize3({(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f});
+            const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
+            const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+            N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
+        }
+    }
+    PbrMaterial m;
+    m.albedo = {baseColor.x, baseColor.y, baseColor.z};
+    m.metallic = metallic;
+    m.roughness = roughness > 0.04f ? roughness : 0.04f;                                // ClampRoughness :476-479
+    f3 lighting = {0.0f, 0.0f, 0.0f};
+    {
+        const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
+        const float intensity = ldcf(cb(D.lights), 12);
+        const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
+        lighting = add3(lighting, pbr_direct(N, V, normalize3({-dir.x, -dir.y, -dir.z}), scale3(color, intensity), m));
+    }
+    const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
+    const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
+    for (uint32_t i = 0; i < numPoint; i++) {
+        const CBytePtr Lp = cb(D.point_lights) + 32u * i;
+        const f3 pos = {ldcf(Lp, 0), ldcf(Lp, 4), ldcf(Lp, 8)};
+        const float radius = ldcf(Lp, 12);
+        const f3 color = {ldcf(Lp, 16), ldcf(Lp, 20), ldcf(Lp, 24)};
+        const float intensity = ldcf(Lp, 28);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(color, intensity), attenuation(dist, radius)), m));
+    }
+    for (uint32_t j = 0; j < numSpot; j++) {
+        const CBytePtr Ls = cb(D.spot_lights) + 48u * j;
+        const f3 pos = {ldcf(Ls, 0), ldcf(Ls, 4), ldcf(Ls, 8)};
+        const float innerCos = ldcf(Ls, 12);
+        const f3 sdir = {ldcf(Ls, 16), ldcf(Ls, 20), ldcf(Ls, 24)};
+        const float outerCos = ldcf(Ls, 28);
+        const f3 color = {ldcf(Ls, 32), ldcf(Ls, 36), ldcf(Ls, 40)};
+        const float intensity = ldcf(Ls, 44);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        const float datt = attenuation(dist, 50.0f);
+        const f3 sd = normalize3(sdir);
+        const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);
+        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(scale3(color, intensity), datt), satt), m));
+    }
+    const float up = N.y * 0.5f + 0.5f;                                                 // CalculateHemisphereAmbient pbr.hlsli:483-492
+    const f3 amb = {0.08f + (0.15f - 0.08f) * up, 0.06f + (0.18f - 0.06f) * up, 0.04f + (0.25f - 0.04f) * up};
+    const float om = 1.0f - m.metallic;
+    const f3 ambient = scale3(scale3(mul3(amb, m.albedo), ao), om);
+    lighting = scale3(lighting, 1.0f + (ao - 1.0f) * 0.5f);                             // lerp(1, ao, 0.5) :311
+    const f3 col = add3(add3(ambient, lighting), emissive);
+    return {col.x, col.y, col.z, baseColor.w};
+}
+
+template <bool PBR>
 __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; Varyings vv[3];
-    const bool full = D.program == 2;
+    const bool full = D.program >= 2;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel
@@ -573,6 +709,7 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
         const f3 col = add3(ambient, lighting);
         return {col.x, col.y, col.z, 1.0f};
     }
+    if (PBR && D.program == 3) return shade_pbr(D, b, vv, worldPos, V, N);
     // pixel/model_full.hlsl:85-150
     const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
@@ -903,7 +1040,8 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
     }
 }
 
-// PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws
+// PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws; 4 = any mix that
+// includes MODEL_PBR draws (its own variant so that the Cook-Torrance code costs the other variants no registers)
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>
@@ -998,8 +1136,8 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
                 const uint32_t tri = prim - D.prim_base;
                 const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
                 if (PROGS == 1) col = shade_triangle_program(D, tri, pxc, pyc);
-                else if (PROGS == 2) col = shade_model_program(D, tri, pxc, pyc);
-                else col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program(D, tri, pxc, pyc);
+                else if (PROGS == 2) col = shade_model_program<false>(D, tri, pxc, pyc);
+                else col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program<PROGS == 4>(D, tri, pxc, pyc);
             }
             todo &= ~__ballot(mine);
         }
@@ -1038,6 +1176,7 @@ static void launch_raster_k(const PassParams& P, uint32_t programs, dim3 grid, h
     const dim3 block(RASTER_THREADS);
     if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P);
     else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P);
+    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel<4, KEYED, TP>), grid, block, 0, stream, P);
     else hipLaunchKernelGGL((raster_kernel<1, KEYED, TP>), grid, block, 0, stream, P);
 }
 

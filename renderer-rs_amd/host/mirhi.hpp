@@ -275,7 +275,7 @@ private:
 // ------------------------------------------------------------------------------------------------
 // crates/rhi/src/pipeline.rs
 // ------------------------------------------------------------------------------------------------
-enum class ShaderProgram { None = -1, Triangle = 0, Model = 1, ModelFull = 2 };   // replaces Shader::from_spirv_file
+enum class ShaderProgram { None = -1, Triangle = 0, Model = 1, ModelFull = 2, ModelPbr = 3 };   // replaces Shader::from_spirv_file
 enum class PrimitiveTopology { PointList = 0, LineList, LineStrip, TriangleList, TriangleStrip, TriangleFan };
 enum class PolygonMode { Fill = 0, Line, Point };
 enum class CullMode { None = 0, Front, Back, FrontAndBack };

@@ -15,7 +15,7 @@ from typing import List, Optional
 
 import numpy as np
 
-PROGRAM_TRIANGLE, PROGRAM_MODEL, PROGRAM_MODEL_FULL = 0, 1, 2
+PROGRAM_TRIANGLE, PROGRAM_MODEL, PROGRAM_MODEL_FULL, PROGRAM_MODEL_PBR = 0, 1, 2, 3
 CULL_NONE, CULL_FRONT, CULL_BACK, CULL_FRONT_AND_BACK = 0, 1, 2, 3
 FRONT_CCW, FRONT_CW = 0, 1
 CMP_NEVER, CMP_LESS, CMP_EQUAL, CMP_LESS_OR_EQUAL, CMP_GREATER, CMP_NOT_EQUAL, CMP_GREATER_OR_EQUAL, CMP_ALWAYS = range(8)
@@ -155,6 +155,18 @@ def material_ubo(base_color=(1.0, 1.0, 1.0, 1.0), metallic=0.0, roughness=0.5, a
     return _v(base_color).tobytes() + np.array([metallic, roughness, ao, 0.0], dtype=f32).tobytes()
 
 
+def pbr_material_ubo(base_color=(1.0, 1.0, 1.0, 1.0), metallic=0.0, roughness=0.5, ao=1.0, normal_scale=1.0,
+                     emissive=(0.0, 0.0, 0.0), alpha_cutoff=0.0, has_base_color=False, has_normal=False,
+                     has_metallic_roughness=False, has_occlusion=False, has_emissive=False) -> bytes:
+    """MaterialData 80 B of the Cook-Torrance program (pixel/model_pbr.hlsl:36-59)."""
+    out = (_v(base_color).tobytes() + np.array([metallic, roughness, ao, normal_scale], dtype=f32).tobytes()
+           + _v(emissive).tobytes() + f32(alpha_cutoff).tobytes()
+           + np.array([has_base_color, has_normal, has_metallic_roughness, has_occlusion, has_emissive, 0, 0, 0],
+                      dtype=np.int32).tobytes())
+    assert len(out) == 80
+    return out
+
+
 def point_light(position, radius, color, intensity) -> bytes:
     """PointLight 32 B (lights.hlsli:27-33 == crates/scene/src/light.rs:31-42)."""
     return _v(position).tobytes() + f32(radius).tobytes() + _v(color).tobytes() + f32(intensity).tobytes()
@@ -206,6 +218,13 @@ class DrawSpec:
     spot_lights: bytes = b""
     albedo_map: Optional[Texture] = None
     normal_map: Optional[Texture] = None
+    metallic_roughness_map: Optional[Texture] = None   # MODEL_PBR only (model_pbr.hlsl:62-95 t2..t4)
+    occlusion_map: Optional[Texture] = None
+    emissive_map: Optional[Texture] = None
+
+    @property
+    def textures(self):
+        return (self.albedo_map, self.normal_map, self.metallic_roughness_map, self.occlusion_map, self.emissive_map)
 
     @property
     def index_type(self) -> int:
@@ -246,7 +265,7 @@ class Scene:
             if d.indices is not None and id(d.indices) not in seen:
                 seen.add(id(d.indices))
                 total += d.indices.size * d.indices.dtype.itemsize
-            for t in (d.albedo_map, d.normal_map):
+            for t in d.textures:
                 if t is not None and id(t) not in seen and t.rgba8.size > 4:
                     seen.add(id(t))
                     total += t.rgba8.size
@@ -611,6 +630,48 @@ def textured_quad_case(width: int = 160, height: int = 120) -> Scene:
     return Scene("textured-quad", width, height, [d], clear_color=(0.0, 0.0, 0.0, 1.0))
 
 
+def pbr_spheres_case(width: int = 224, height: int = 144) -> Scene:
+    """Cook-Torrance program (pixel/model_pbr.hlsl): five draws covering every material switch -- factors only,
+    all five textures, metallic, a constant-alpha draw the cutoff removes, and a textured draw whose cutoff is
+    below every possible texel alpha."""
+    rng = PCG32(0xB0B)
+    view, proj, cam = default_camera(width, height, eye=(0.0, 0.4, 4.2))
+    light = light_ubo(direction=(0.3, -0.8, -0.5), intensity=1.6, color=(1.0, 0.96, 0.9), num_point=2, num_spot=1)
+    points = point_light((1.5, 1.2, 2.0), 9.0, (0.5, 0.7, 1.0), 6.0) + point_light((-2.0, 0.3, 1.5), 7.0, (1.0, 0.5, 0.3), 4.0)
+    spots = spot_light((0.0, 2.5, 2.5), 0.93, (0.0, -0.7, -0.7), 0.75, (0.9, 1.0, 0.8), 9.0)
+    base = _procedural_texture(2, 32, 7)
+    nm = np.zeros((16, 16, 4), dtype=np.uint8)
+    r = rng.uniform(16 * 16 * 2).reshape(16, 16, 2)
+    nm[:, :, 0] = (128 + (r[:, :, 0] - 0.5) * 90).astype(np.uint8)
+    nm[:, :, 1] = (128 + (r[:, :, 1] - 0.5) * 90).astype(np.uint8)
+    nm[:, :, 2] = 225
+    nm[:, :, 3] = 255
+    mr = (rng.uniform(8 * 8 * 4).reshape(8, 8, 4) * 255).astype(np.uint8)
+    occ = (128 + rng.uniform(8 * 8 * 4).reshape(8, 8, 4) * 127).astype(np.uint8)
+    emi = (rng.uniform(4 * 4 * 4).reshape(4, 4, 4) * 255).astype(np.uint8)
+    sphere = displaced_sphere(20, 14, width, height, seed=11).draws[0]
+    mats = [
+        dict(material=pbr_material_ubo((0.8, 0.3, 0.2, 1.0), 0.0, 0.45, 0.9, emissive=(0.02, 0.0, 0.05))),
+        dict(material=pbr_material_ubo((1.0, 0.9, 0.8, 0.7), 0.9, 0.8, 1.0, normal_scale=0.7, emissive=(0.5, 0.4, 0.1),
+                                       has_base_color=True, has_normal=True, has_metallic_roughness=True,
+                                       has_occlusion=True, has_emissive=True),
+             albedo_map=base, normal_map=Texture(nm), metallic_roughness_map=Texture(mr), occlusion_map=Texture(occ),
+             emissive_map=Texture(emi)),
+        dict(material=pbr_material_ubo((0.95, 0.8, 0.4, 1.0), 1.0, 0.02, 1.0)),                       # roughness clamp 0.04
+        dict(material=pbr_material_ubo((0.1, 0.9, 0.1, 0.3), 0.0, 0.5, 1.0, alpha_cutoff=0.5)),      # dropped by the cutoff
+        dict(material=pbr_material_ubo((0.3, 0.4, 0.9, 0.6), 0.2, 0.6, 0.7, alpha_cutoff=-0.25, has_base_color=True),
+             albedo_map=base),
+    ]
+    draws = []
+    for k, extra in enumerate(mats):
+        x = -2.4 + 1.2 * k
+        model = trs((0.55, 0.55, 0.55), quat_axis_angle((0.3, 1.0, 0.1), 0.4 * k), (x, 0.25 * (k % 2), -0.3 * k))
+        draws.append(DrawSpec(vertices=sphere.vertices, stride=48, count=sphere.count, indices=sphere.indices,
+                              program=PROGRAM_MODEL_PBR, cull_mode=CULL_BACK, front_face=sphere.front_face, camera=cam,
+                              object=object_ubo(model), light=light, point_lights=points, spot_lights=spots, **extra))
+    return Scene("pbr-spheres", width, height, draws, clear_color=(0.02, 0.02, 0.03, 1.0))
+
+
 def gltf_model(path: str, width: int = 1920, height: int = 1080, program: int = PROGRAM_MODEL_FULL,
                eye=(0.0, 0.0, 3.2), yaw: float = 0.4) -> Scene:
     """A glTF asset through the reference's loader semantics (gltf.load) -> `Vertex` streams, lit like config 3:
@@ -640,6 +701,7 @@ SMALL_CASES = {
     "multi_draw": multi_draw_case,
     "huge": huge_triangle_case,
     "textured": textured_quad_case,
+    "pbr": pbr_spheres_case,
     "random_small": lambda: random_triangles(300, 320, 200, seed=42, rmin=2, rmax=40),
     "sphere_small": lambda: displaced_sphere(24, 17, 256, 160, seed=3),
 }

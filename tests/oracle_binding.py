@@ -30,6 +30,7 @@ class OracleDraw(C.Structure):
         ("camera", C.c_void_p), ("object", C.c_void_p), ("light_ubo", C.c_void_p), ("material", C.c_void_p),
         ("point_lights", C.c_void_p), ("spot_lights", C.c_void_p),
         ("albedo_map", OracleTexture), ("normal_map", OracleTexture),
+        ("metallic_roughness_map", OracleTexture), ("occlusion_map", OracleTexture), ("emissive_map", OracleTexture),
     ]
 
 
@@ -62,6 +63,10 @@ def lib():
         L.oracle_srgb8.argtypes = [C.c_float]
         L.oracle_attenuation.restype = C.c_float
         L.oracle_attenuation.argtypes = [C.c_float, C.c_float]
+        L.oracle_distribution_ggx.restype = C.c_float
+        L.oracle_distribution_ggx.argtypes = [C.c_float, C.c_float]
+        L.oracle_geometry_schlick_ggx.restype = C.c_float
+        L.oracle_geometry_schlick_ggx.argtypes = [C.c_float, C.c_float]
         L.oracle_roughness_to_shininess.restype = C.c_float
         L.oracle_roughness_to_shininess.argtypes = [C.c_float]
         L.oracle_glam_determinant.restype = C.c_float
@@ -110,7 +115,9 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
             k, addr = _buf(src)
             keep.append(k)
             setattr(od, name, addr)
-        for name, tex in (("albedo_map", d.albedo_map), ("normal_map", d.normal_map)):
+        for name, tex in (("albedo_map", d.albedo_map), ("normal_map", d.normal_map),
+                          ("metallic_roughness_map", d.metallic_roughness_map), ("occlusion_map", d.occlusion_map),
+                          ("emissive_map", d.emissive_map)):
             if tex is not None:
                 arr = np.ascontiguousarray(tex.rgba8)
                 keep.append(arr)

@@ -288,3 +288,31 @@ def test_big_list_and_bin_spill_paths(mirhi, oracle, device, scenes):
     assert np.array_equal(got["prim"], ref["prim"])
     res.destroy()
     f.destroy()
+
+
+def test_pbr_textured_alpha_cutoff_is_reported(mirhi, oracle, device, scenes):
+    """pixel/model_pbr.hlsl:174-178: a base-colour texture whose texel alpha could straddle alphaCutoff needs a
+    per-fragment discard, which the path does not do: the fence reports a PipelineError and the draw is skipped
+    (the other draws of the frame are still exact)."""
+    sc = scenes.SMALL_CASES["pbr"]()
+    sc.draws[4].material = scenes.pbr_material_ubo((0.3, 0.4, 0.9, 0.6), alpha_cutoff=0.25, has_base_color=True)
+    res = mirhi.SceneResources(device, sc, want_prim=True)
+    f = mirhi.Fence(device)
+    res.render(f)
+    with pytest.raises(mirhi.RhiError) as e:
+        f.wait()
+    assert e.value.code == 9   # MIRHI_ERR_PIPELINE
+    assert "alpha cutoff" in e.value.message
+    out = res.read()
+    del sc.draws[4]
+    ref = oracle.render(sc, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"])
+    f.destroy()
+    res.destroy()
+    # the next clean frame clears the condition
+    res = mirhi.SceneResources(device, scenes.hello_triangle(64, 64))
+    f = mirhi.Fence(device)
+    res.render(f)
+    f.wait()
+    f.destroy()
+    res.destroy()

@@ -103,3 +103,72 @@ def test_hostile_vertex_values(mirhi, oracle, device, scenes, seed):
     cov = ref["prim"] != 0xFFFFFFFF
     assert np.array_equal(out["depth"].view(np.uint32)[cov], ref["depth"].view(np.uint32)[cov])
     assert np.array_equal(np.isnan(out["color"]), np.isnan(ref["rgba"]))
+
+
+def _random_pbr_scene(scenes, seed):
+    """Cook-Torrance draws with random factors, texture switches and lights (pixel/model_pbr.hlsl)."""
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(40, 260)), int(rng.integers(30, 200))
+
+    def tex(n):
+        return scenes.Texture(rng.integers(0, 256, (n, n, 4), dtype=np.uint8))
+
+    eye = (float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(1.2, 4.0)))
+    view = scenes.look_at_rh(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+    proj = scenes.projection_vulkan(math.radians(float(rng.uniform(35, 90))), W / H, 0.1, 50.0)
+    cam = scenes.camera_ubo(view, proj, eye)
+    npnt, nspt = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+    points = b"".join(scenes.point_light(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(2, 12)), tuple(rng.uniform(0, 1, 3)),
+                                         float(rng.uniform(0, 8))) for _ in range(npnt))
+    spots = b"".join(scenes.spot_light(tuple(rng.uniform(-3, 3, 3)), float(rng.uniform(0.85, 0.99)), tuple(rng.normal(size=3)),
+                                       float(rng.uniform(0.5, 0.84)), tuple(rng.uniform(0, 1, 3)), float(rng.uniform(0, 10)))
+                     for _ in range(nspt))
+    light = scenes.light_ubo(direction=tuple(rng.normal(size=3)), intensity=float(rng.uniform(0, 3)), color=tuple(rng.uniform(0, 1, 3)),
+                             num_point=npnt, num_spot=nspt)
+    draws = []
+    for _ in range(int(rng.integers(1, 4))):
+        s = scenes.displaced_sphere(int(rng.integers(3, 14)), int(rng.integers(3, 11)), W, H, seed=int(rng.integers(1, 1 << 30)),
+                                    program=scenes.PROGRAM_MODEL_PBR).draws[0]
+        flags = rng.random(5) < 0.5
+        alpha = float(rng.uniform(0.2, 1.0))
+        # cutoff only where one decision covers the draw: untextured (either side), or textured with cutoff <= 0
+        cutoff = float(rng.choice([0.0, alpha - 0.1, alpha + 0.1])) if not flags[0] else float(rng.choice([0.0, -0.5]))
+        s.material = scenes.pbr_material_ubo(tuple(rng.uniform(0, 1, 3)) + (alpha,), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)),
+                                             float(rng.uniform(0.3, 1)), normal_scale=float(rng.uniform(0.2, 1.5)),
+                                             emissive=tuple(rng.uniform(0, 0.5, 3)), alpha_cutoff=cutoff,
+                                             has_base_color=flags[0], has_normal=flags[1], has_metallic_roughness=flags[2],
+                                             has_occlusion=flags[3], has_emissive=flags[4])
+        s.albedo_map = tex(int(rng.integers(1, 20))) if flags[0] and rng.random() < 0.9 else None
+        s.normal_map = tex(int(rng.integers(1, 20))) if flags[1] and rng.random() < 0.9 else None
+        s.metallic_roughness_map = tex(int(rng.integers(1, 20))) if flags[2] else None
+        s.occlusion_map = tex(int(rng.integers(1, 20))) if flags[3] else None
+        s.emissive_map = tex(int(rng.integers(1, 20))) if flags[4] else None
+        s.camera, s.light, s.point_lights, s.spot_lights = cam, light, points, spots
+        s.object = scenes.object_ubo(scenes.trs(tuple(rng.uniform(0.4, 1.2, 3)), scenes.quat_axis_angle(rng.normal(size=3), float(rng.uniform(0, 6))),
+                                                tuple(rng.uniform(-0.8, 0.8, 3))))
+        s.cull_mode = int(rng.integers(0, 3))
+        draws.append(s)
+    if rng.random() < 0.5:      # mix with a TRIANGLE-program draw: the variant that carries every program
+        n = int(rng.integers(1, 30))
+        p = rng.uniform(-1, 1, (n, 1, 2)) + rng.normal(0, 0.2, (n, 3, 2))
+        verts = np.concatenate([p, rng.uniform(0, 1, (n, 3, 1)), rng.uniform(0, 1, (n, 3, 3))], axis=2).astype(np.float32).reshape(n * 3, 6)
+        draws.append(scenes.DrawSpec(vertices=verts, stride=24, count=3 * n, program=scenes.PROGRAM_TRIANGLE, cull_mode=scenes.CULL_NONE))
+    return scenes.Scene(f"fuzz-pbr-{seed}", W, H, draws, clear_color=tuple(rng.uniform(0, 1, 3)) + (1.0,))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_pbr_against_oracle(mirhi, oracle, device, scenes, seed):
+    scene = _random_pbr_scene(scenes, 3000 + seed)
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"]), f"{scene.name}: winning primitive differs"
+    cov = ref["prim"] != 0xFFFFFFFF
+    assert np.array_equal(out["depth"].view(np.uint32)[cov], ref["depth"].view(np.uint32)[cov]), f"{scene.name}: depth bits differ"
+    a, b = out["color"], ref["rgba"]
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan)
+    err = np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b)))
+    assert err.max() < 1e-4, f"{scene.name}: max |dRGBA| {err.max()}"

@@ -187,3 +187,100 @@ def test_near_clip_is_watertight(oracle, scenes):
     assert cov.sum() > 1000 and not np.isnan(r["rgba"]).any()
     # below the horizon every pixel of the bottom rows is ground
     assert cov[-1].all() and cov[-20].all()
+
+
+# ------------------------------------------------------------------------------------------------
+# K7: Cook-Torrance program (pbr.hlsli, pixel/model_pbr.hlsl) against closed forms evaluated in float64
+# ------------------------------------------------------------------------------------------------
+def _pbr_direct64(N, V, L, radiance, albedo, metallic, roughness):
+    """pbr.hlsli:292-333 written from the published Cook-Torrance / GGX / Smith / Schlick formulas."""
+    H = (V + L) / np.linalg.norm(V + L)
+    a2 = roughness ** 4
+    ndh, ndv, ndl = max(N @ H, 0.0), max(N @ V, 0.0), max(N @ L, 0.0)
+    D = a2 / max(math.pi * (ndh * ndh * (a2 - 1.0) + 1.0) ** 2, 1e-4)
+    k = (roughness + 1.0) ** 2 / 8.0
+    G = (ndv / max(ndv * (1 - k) + k, 1e-4)) * (ndl / max(ndl * (1 - k) + k, 1e-4))
+    F0 = 0.04 + (albedo - 0.04) * metallic
+    F = F0 + (1.0 - F0) * (1.0 - min(max(H @ V, 0.0), 1.0)) ** 5
+    spec = D * G * F / (4.0 * ndv * ndl + 1e-4)
+    kD = (1.0 - F) * (1.0 - metallic)
+    return (kD * albedo / math.pi + spec) * radiance * ndl
+
+
+def test_k7_pbr_brdf_terms(oracle):
+    L = oracle.lib()
+    # D(N.H = 1, roughness 0.5) = a^2 / (pi a^4) = 1 / (pi * 0.0625)
+    assert L.oracle_distribution_ggx(1.0, 0.5) == pytest.approx(1.0 / (math.pi * 0.0625), rel=1e-6)
+    # fully rough: a = 1 -> D = 1/pi for every N.H
+    for x in (0.0, 0.3, 1.0):
+        assert L.oracle_distribution_ggx(x, 1.0) == pytest.approx(1.0 / math.pi, rel=1e-6)
+    # EPSILON clamp of the denominator (pbr.hlsli:18,68): a^2 = 1e-8 at N.H = 1 gives pi * 1e-16 -> clamped to 1e-4
+    assert L.oracle_distribution_ggx(1.0, 0.01) == pytest.approx(1e-8 / 1e-4, rel=1e-5)
+    # Schlick-GGX: G(1, r) = 1; G(0.5, 1) = 0.5 / (0.5 * 0.5 + 0.5); G(0, r) = 0
+    assert L.oracle_geometry_schlick_ggx(1.0, 0.3) == pytest.approx(1.0, rel=1e-6)
+    assert L.oracle_geometry_schlick_ggx(0.5, 1.0) == pytest.approx(0.5 / 0.75, rel=1e-6)
+    assert L.oracle_geometry_schlick_ggx(0.0, 0.7) == 0.0
+
+
+@pytest.mark.parametrize("metallic,roughness", [(0.0, 0.5), (1.0, 0.3), (0.4, 0.01)])
+def test_k7_pbr_pixel_closed_form(oracle, scenes, metallic, roughness):
+    """A z = 0 quad with normal +z, one directional and one point light, no textures: every centre-row pixel must
+    equal the float64 evaluation of model_pbr.hlsl:159-320 at the ray/plane intersection of that pixel."""
+    W = H = 48
+    pos = np.array([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], dtype=np.float32)
+    verts = np.zeros((4, 12), dtype=np.float32)
+    verts[:, 0:3] = pos; verts[:, 3:6] = [0, 0, 1]; verts[:, 8:12] = [1, 0, 0, 1]
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    eye = np.array([0.0, 0.0, 3.0])
+    fov = math.radians(45.0)
+    view = scenes.look_at_rh(tuple(eye), (0, 0, 0), (0, 1, 0))
+    proj = scenes.projection_vulkan(fov, 1.0, 0.1, 100.0)
+    albedo = np.array([0.8, 0.5, 0.3])
+    emissive = np.array([0.01, 0.02, 0.03])
+    ao = 0.8
+    ldir = np.array([0.3, -0.2, -1.0])
+    lcol, lint = np.array([1.0, 0.9, 0.8]), 2.0
+    ppos, prad, pcol, pint = np.array([1.0, 1.0, 1.5]), 6.0, np.array([0.4, 0.6, 1.0]), 5.0
+    d = scenes.DrawSpec(vertices=verts, stride=48, count=6, indices=idx, program=scenes.PROGRAM_MODEL_PBR,
+                        cull_mode=scenes.CULL_NONE, camera=scenes.camera_ubo(view, proj, tuple(eye)),
+                        object=scenes.object_ubo(np.eye(4, dtype=np.float32)),
+                        light=scenes.light_ubo(direction=tuple(ldir), intensity=lint, color=tuple(lcol), num_point=1),
+                        point_lights=scenes.point_light(tuple(ppos), prad, tuple(pcol), pint),
+                        material=scenes.pbr_material_ubo(tuple(albedo) + (0.9,), metallic, roughness, ao, emissive=tuple(emissive)))
+    r = oracle.render(scenes.Scene("k7", W, H, [d]))
+    rough = max(roughness, 0.04)
+    N = np.array([0.0, 0.0, 1.0])
+    t = math.tan(fov / 2)
+    for px in range(4, W, 5):
+        py = H // 2
+        # pixel centre -> NDC (Vulkan y down, projection_vulkan flips y) -> ray from the eye -> plane z = 0
+        nx, ny = (px + 0.5) / W * 2 - 1, (py + 0.5) / H * 2 - 1
+        ray = np.array([nx * t, -ny * t, -1.0])
+        wp = eye + ray * (eye[2] / 1.0)
+        V = (eye - wp) / np.linalg.norm(eye - wp)
+        Ld = -ldir / np.linalg.norm(ldir)
+        lighting = _pbr_direct64(N, V, Ld, lcol * lint, albedo, metallic, rough)
+        lv = ppos - wp
+        dist = np.linalg.norm(lv)
+        att = (1.0 / (dist * dist + 1.0)) * min(max(1.0 - dist / prad, 0.0), 1.0) ** 2
+        lighting = lighting + _pbr_direct64(N, V, lv / dist, pcol * pint * att, albedo, metallic, rough)
+        up = N[1] * 0.5 + 0.5
+        amb = np.array([0.08, 0.06, 0.04]) + (np.array([0.15, 0.18, 0.25]) - np.array([0.08, 0.06, 0.04])) * up
+        want = amb * albedo * ao * (1.0 - metallic) + lighting * (1.0 + (ao - 1.0) * 0.5) + emissive
+        got = r["rgba"][py, px]
+        assert r["prim"][py, px] != 0xFFFFFFFF
+        assert got[:3] == pytest.approx(want, rel=2e-4, abs=2e-5), (px, got, want)
+        assert got[3] == pytest.approx(0.9)
+
+
+def test_k7_pbr_alpha_cutoff(oracle, scenes):
+    """model_pbr.hlsl:174-178: constant alpha below the cutoff removes the draw; a textured base colour whose texels
+    could straddle the cutoff is refused (per-fragment discard is outside the restated path)."""
+    sc = scenes.SMALL_CASES["pbr"]()
+    r = oracle.render(sc)
+    nt = sc.draws[0].num_triangles
+    drawn = set(np.unique(r["prim"][r["prim"] != 0xFFFFFFFF] // nt).tolist())
+    assert drawn == {0, 1, 2, 4}
+    sc.draws[4].material = scenes.pbr_material_ubo((0.3, 0.4, 0.9, 0.6), alpha_cutoff=0.25, has_base_color=True)
+    with pytest.raises(RuntimeError, match="oracle_render failed: 2"):
+        oracle.render(sc)
