@@ -1001,11 +1001,13 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
         if (tid < RASTER_CHUNK && i < n_total) {
-            const uint4 w2 = list[(size_t)i * 3u + 2u];
+            // all three words are requested together: one memory round trip, not two (a bin holds only records whose
+            // box overlaps the tile, so the box test below almost never saves the first two loads)
+            const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
             const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
             const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
             hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
-            if (hit) hit = make_tile_rec(rec, box, list[(size_t)i * 3u], list[(size_t)i * 3u + 1u], w2, (int32_t)tx, (int32_t)ty);
+            if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)tx, (int32_t)ty);
         }
         bool small = false, boxed = false;
         if (hit) {
@@ -1045,7 +1047,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams P) {
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 : 8)) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams P) {
     __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
@@ -1104,19 +1106,59 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
     STAMP(3);
     if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
+    // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
+    if (TP) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long kreg = ((unsigned long long)st.zk[b] << 32) | st.idk[b];
+            const unsigned long long klds = lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK];
+            const unsigned long long kmin = klds < kreg ? klds : kreg;
+            st.zk[b] = (uint32_t)(kmin >> 32); st.idk[b] = (uint32_t)kmin;
+        }
+    }
+    // flat colours of all four owned pixels are requested before the first one is used (four overlapping loads
+    // instead of four dependent round trips in the loop below)
+    uint32_t flat4[4] = {0u, 0u, 0u, 0u};
+    if (PROGS == 1 && P.flat_color && !P.depth_load) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool won = !(st.zk[b] == P.init_zk && st.idk[b] == P.init_idk);
+            if (won) flat4[b] = P.flat_color[P.idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b]];
+        }
+    }
+    // Fast exit for the headline shape of work: every covered pixel of this wave belongs to a flat-coloured
+    // triangle whose packed colour the geometry kernel already produced, and only the 8-bit colour target is
+    // written.  Same values as the general loop below, a fraction of its instructions.
+    if (PROGS == 1 && P.flat_color && !P.depth_load && P.color_format != 2 && !P.prim_out && !(P.depth && P.depth_store)) {
+        bool need_shade = false;
+        uint32_t outc[4]; bool won4[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            won4[b] = !(st.zk[b] == P.init_zk && st.idk[b] == P.init_idk);
+            need_shade = need_shade || (won4[b] && flat4[b] == 0u);
+            outc[b] = won4[b] ? flat4[b] : P.clear_packed;
+        }
+        if (__ballot(need_shade) == 0ull) {
+            const bool whole = (tx + 1u) * TILE <= P.width && (ty + 1u) * TILE <= P.height;     // wave-uniform
+            uint32_t* dst = reinterpret_cast<uint32_t*>(P.color) + (size_t)py0 * P.width + px0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+                const bool inb = whole || (px < P.width && py < P.height);
+                if (inb && (won4[b] || !P.color_load)) dst[(size_t)(b >> 1) * BLOCK * P.width + (size_t)(b & 1) * BLOCK] = outc[b];
+            }
+            STAMP(4);
+            return;
+        }
+    }
 #pragma unroll 1
     for (int b = 0; b < 4; b++) {
         const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
         const bool inb = px < P.width && py < P.height;
         uint32_t izk, iidk, zorig;
         init_key(P, px, py, inb, izk, iidk, zorig);
-        const uint32_t zkr = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
-        const uint32_t idr = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
-        // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
-        const unsigned long long kreg = ((unsigned long long)zkr << 32) | idr;
-        const unsigned long long klds = TP ? lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK] : ~0ull;
-        const unsigned long long kmin = klds < kreg ? klds : kreg;
-        const uint32_t zkb = (uint32_t)(kmin >> 32), idb = (uint32_t)kmin;
+        const uint32_t zkb = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
+        const uint32_t idb = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
         const bool none = !inb || ((zkb == izk) && (idb == iidk));
         const size_t pix = (size_t)py * P.width + px;
         const uint32_t prim = none ? NO_PRIM : (P.idflip ? (MAX_PRIM_ID - idb) : idb);
@@ -1124,7 +1166,10 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : 7) : (PR
         // waterfall over the draws present in this wave: the draw descriptor stays wave-uniform (scalar loads)
         const uint32_t mydraw = none ? 0xFFFFFFFFu : (P.num_draws > 1 ? find_draw(P, prim) : 0u);
         uint32_t flat = 0;
-        if (PROGS == 1 && P.flat_color && !none) flat = P.flat_color[prim];      // alpha is 255 whenever it is set
+        if (PROGS == 1 && P.flat_color && !none) {      // alpha is 255 whenever it is set
+            if (P.depth_load) flat = P.flat_color[prim];
+            else flat = b == 0 ? flat4[0] : (b == 1 ? flat4[1] : (b == 2 ? flat4[2] : flat4[3]));
+        }
         uint64_t todo = __ballot(!none && flat == 0u);
         while (todo) {
             const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);

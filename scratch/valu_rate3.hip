@@ -1,0 +1,101 @@
+// third probe: the per-record update loop of raster_record (current form and alternatives), records broadcast from LDS.
+// Reports cycles per (record, wave) visit with all four 8x8 blocks enabled.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+struct PixelState { uint32_t zk[4], idk[4]; };
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t d; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+template <int VAR>
+__device__ __forceinline__ void visit(const uint4* lds_rec, uint32_t j, int32_t ix0, int32_t iy0, float fix0, float fiy0, PixelState& st) {
+    const uint4 w0 = lds_rec[j * 4], w1 = lds_rec[j * 4 + 1], w2 = lds_rec[j * 4 + 2], w3 = lds_rec[j * 4 + 3];
+    const int32_t A0 = (int32_t)w0.w, A1 = (int32_t)w1.x, A2 = (int32_t)w1.y, B0 = (int32_t)w1.z, B1 = (int32_t)w1.w, B2 = (int32_t)w2.x;
+    const float z0 = __uint_as_float(w2.w), zx = __uint_as_float(w3.x), zy = __uint_as_float(w3.y);
+    const uint32_t idk = w3.z;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(w3.w);
+    const int32_t s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)w0.x));
+    const int32_t s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)w0.y));
+    const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)w0.z));
+    const float dx0 = fix0 + __uint_as_float(w2.y), dy0 = fiy0 + __uint_as_float(w2.z);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int bx = b & 1, by = b >> 1;
+        if (!(m & (1u << (by * 4 + bx)))) continue;
+        const int32_t S0 = s0 + (A0 * bx + B0 * by) * 8, S1 = s1 + (A1 * bx + B1 * by) * 8, S2 = s2 + (A2 * bx + B2 * by) * 8;
+        const bool inside = (S0 | S1 | S2) >= 0;
+        const float dx = dx0 + (float)(bx * 8), dy = dy0 + (float)(by * 8);
+        const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+        uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+        if (VAR == 0) {          // current: 64-bit compare + two selects
+            const uint64_t key = ((uint64_t)zk << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+            const bool upd = inside && key < cur;
+            st.zk[b] = upd ? zk : st.zk[b]; st.idk[b] = upd ? idk : st.idk[b];
+        } else if (VAR == 1) {   // branchy form: lets the compiler use exec-masked moves
+            const uint64_t key = ((uint64_t)zk << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+            if (inside && key < cur) { st.zk[b] = zk; st.idk[b] = idk; }
+        } else if (VAR == 2) {   // outside lanes get the largest key: no mask AND, selects keyed on the compare alone
+            const uint32_t zke = inside ? zk : 0xFFFFFFFFu;
+            const uint64_t key = ((uint64_t)zke << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+            const bool upd = key < cur;
+            st.zk[b] = upd ? zke : st.zk[b]; st.idk[b] = upd ? idk : st.idk[b];
+        } else if (VAR == 3) {   // sign trick: OR the edge sign bit into the depth key (covered -> unchanged, outside -> >= 0x80000000)
+            const uint32_t zke = zk | ((uint32_t)(S0 | S1 | S2) & 0x80000000u);
+            const uint64_t key = ((uint64_t)zke << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
+            const bool upd = key < cur;
+            st.zk[b] = upd ? zke : st.zk[b]; st.idk[b] = upd ? idk : st.idk[b];
+        }
+    }
+}
+template <int VAR>
+__global__ __launch_bounds__(256) void k(uint32_t* out, int nrec, int iters, const uint4* recs) {
+    __shared__ uint4 lds_rec[64 * 4];
+    lds_rec[threadIdx.x] = recs[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const int32_t ix0 = (q & 1) * 16 + (lane & 7), iy0 = (q >> 1) * 16 + (lane >> 3);
+    PixelState st;
+    for (int b = 0; b < 4; b++) { st.zk[b] = 0x3f800000u; st.idk[b] = 0xffffffffu; }
+    for (int i = 0; i < iters; i++)
+        for (int j = 0; j < nrec; j++) visit<VAR>(lds_rec, (uint32_t)j, ix0, iy0, (float)ix0, (float)iy0, st);
+    uint32_t h = 0;
+    for (int b = 0; b < 4; b++) h ^= st.zk[b] * 31u + st.idk[b];
+    out[blockIdx.x * 256 + threadIdx.x] = h;
+}
+template <int VAR> uint32_t run(const char* name, uint32_t* d, const uint4* recs) {
+    const int iters = 400, nrec = 64, wg_per_cu = 4;     // 4 waves / SIMD
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL(k<VAR>, dim3(256 * wg_per_cu), dim3(256), 0, 0, d, nrec, 2, recs);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(k<VAR>, dim3(256 * wg_per_cu), dim3(256), 0, 0, d, nrec, iters, recs);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    static uint32_t h[256 * 4 * 256];
+    (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    uint32_t x = 0; for (uint32_t v : h) x = x * 1000003u + v;
+    printf("%-40s %.1f cycles@2.4GHz per record visit per SIMD   checksum %08x\n", name, ms * 1e6 / ((double)iters * nrec) / wg_per_cu * 2.4, x);
+    return x;
+}
+int main() {
+    uint32_t* d; (void)hipMalloc(&d, 256 * 4 * 256 * 4);
+    uint4 h[256];
+    uint32_t s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+    for (int j = 0; j < 64; j++) {
+        const int32_t A0 = (int32_t)(rnd() % 8192) - 4096, A1 = (int32_t)(rnd() % 8192) - 4096, A2 = -(A0 + A1);
+        const int32_t B0 = (int32_t)(rnd() % 8192) - 4096, B1 = (int32_t)(rnd() % 8192) - 4096, B2 = -(B0 + B1);
+        h[j * 4 + 0] = make_uint4(rnd() % 100000, rnd() % 100000, rnd() % 100000, (uint32_t)A0);
+        h[j * 4 + 1] = make_uint4((uint32_t)A1, (uint32_t)A2, (uint32_t)B0, (uint32_t)B1);
+        float dxt = -3.5f, dyt = 2.25f, z0 = (rnd() % 1000) / 1000.0f, zx = 0.001f, zy = -0.002f;
+        h[j * 4 + 2] = make_uint4((uint32_t)B2, *(uint32_t*)&dxt, *(uint32_t*)&dyt, *(uint32_t*)&z0);
+        h[j * 4 + 3] = make_uint4(*(uint32_t*)&zx, *(uint32_t*)&zy, (uint32_t)j, 0xFFFFu);
+    }
+    uint4* recs; (void)hipMalloc(&recs, sizeof h); (void)hipMemcpy(recs, h, sizeof h, hipMemcpyHostToDevice);
+    const uint32_t c0 = run<0>("current (cmp_u64 + s_and + 2 cndmask)", d, recs);
+    const uint32_t c1 = run<1>("branchy update", d, recs);
+    run<2>("outside -> max key (select on inside)", d, recs);
+    run<3>("edge sign bit ORed into depth key", d, recs);
+    printf("variants 0/1 agree: %d (2/3 store a different non-covered key by construction)\n", c0 == c1);
+    return 0;
+}
