@@ -164,7 +164,7 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     dev = m.Device(local_rank, stream=stream)
-    nfif = 1 if split else max(1, min(4, args.frames_in_flight))
+    nfif = 1 if split else max(1, min(8, args.frames_in_flight))
     dev.set_queue_lanes(nfif)
     if split:
         dev.set_tile_split(rank, world)

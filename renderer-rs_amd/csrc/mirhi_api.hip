@@ -135,6 +135,7 @@ struct Workspace {
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
+    PassParams* params = nullptr; size_t params_bytes = 0;   // two copies per scope (big-list counter parity 0 / 1), read by the kernels
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
     uint32_t* status_host = nullptr;                             // pinned, device-mapped: [status bits, big-list length]
@@ -239,7 +240,7 @@ extern "C" mirhi_result mirhi_device_wait_idle(mirhi_device* dev) {
 }
 extern "C" mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t lanes) {
     NULL_CHECK(dev, "device");
-    if (lanes < 1 || lanes > 4) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lanes must be 1..4 (got %u)", lanes);
+    if (lanes < 1 || lanes > 8) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lanes must be 1..8 (got %u)", lanes);
     mirhi_result r = sync_all_lanes(dev);
     if (r != MIRHI_OK) return r;
     while (dev->lanes.size() > lanes) { (void)hipStreamDestroy(dev->lanes.back()); dev->lanes.pop_back(); }
@@ -543,6 +544,7 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.counters) (void)hipFree(w.counters);
     if (w.big_recs) (void)hipFree(w.big_recs);
     if (w.vs_jobs) (void)hipFree(w.vs_jobs);
+    if (w.params) (void)hipFree(w.params);
     if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.flat_color) (void)hipFree(w.flat_color);
     if (w.status_host) (void)hipHostFree(w.status_host);
@@ -901,6 +903,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     }
     if ((r = grow(&w.vs_out, &w.vs_out_bytes, vs_bytes_max ? vs_bytes_max : 256)) != MIRHI_OK) return r;
     if ((r = grow(&w.vs_jobs, &w.vs_jobs_bytes, (jobs_total ? jobs_total : 1) * sizeof(VsJob))) != MIRHI_OK) return r;
+    if ((r = grow(&w.params, &w.params_bytes, (cmd->passes.size() ? cmd->passes.size() : 1) * 2 * sizeof(PassParams))) != MIRHI_OK) return r;
     std::vector<VsJob> all_jobs;
     all_jobs.reserve(jobs_total);
     size_t flat_tris = 0;
@@ -983,6 +986,19 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     if (!all_jobs.empty()) {
         HIP_TRY(hipMemcpyAsync(w.vs_jobs, all_jobs.data(), all_jobs.size() * sizeof(VsJob), hipMemcpyHostToDevice, stream));
     }
+    // the kernels read their parameters from device memory: copy 2*pi + parity of scope pi appends large triangles to
+    // counter `parity` and re-arms the other one for the scope that follows on this workspace
+    std::vector<PassParams> dev_params;
+    for (const PassParams& P0 : cmd->plan) {
+        for (uint32_t parity = 0; parity < 2; parity++) {
+            PassParams P = P0;
+            P.big_count = w.big_counts + parity;
+            P.big_count_next = w.big_counts + (parity ^ 1u);
+            dev_params.push_back(P);
+        }
+    }
+    if (!dev_params.empty())
+        HIP_TRY(hipMemcpyAsync(w.params, dev_params.data(), dev_params.size() * sizeof(PassParams), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     dev->stats.workspace_bytes = w.bytes();
     cmd->state = CMD_EXECUTABLE;
@@ -1014,20 +1030,21 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
-            PassParams P = c->plan[pi];
-            P.big_count = c->ws.big_counts + c->ws.parity;          // alternate the big-list counter: the raster
-            P.big_count_next = c->ws.big_counts + (c->ws.parity ^ 1u); // kernel zeroes the other one for the next scope
+            const PassParams& P = c->plan[pi];
+            // alternate the big-list counter: the raster kernel zeroes the other one for the next scope
+            const PassParams* dp = c->ws.params + 2 * pi + c->ws.parity;
+            uint32_t* big_count = c->ws.big_counts + c->ws.parity;
             c->ws.parity ^= 1u;
             EventPair ev{};
             if (dev->profiling) { mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r; }
-            HIP_TRY(launch_vertex(P, stream));
-            HIP_TRY(launch_geometry(P, stream));
+            HIP_TRY(launch_vertex(P, dp, stream));
+            HIP_TRY(launch_geometry(P, dp, stream));
             if (dev->profiling) {
                 HIP_TRY(hipEventRecord(ev.b, stream));
                 dev->pending[MIRHI_KERNEL_GEOMETRY].push_back(ev);
                 mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r;
             }
-            HIP_TRY(launch_raster(P, c->plan_programs[pi], stream));
+            HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream));
             if (dev->profiling) { HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev); }
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += P.total_tris;

@@ -23,6 +23,7 @@ constexpr int MAX_BIN_SPAN = 4;       // triangles spanning more than 4x4 tiles 
 constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay inside +-2^22 sub-pixels
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t MAX_PRIM_ID = 0xFFFFFFFDu;
+constexpr uint32_t GEOM_WIDE_MAX_SLOTS = 65536u;   // scopes up to this many (padded) triangles use the 16-lanes-per-triangle geometry kernel
 
 enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u };
 
@@ -114,6 +115,14 @@ struct PassParams {
                                       // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
     uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
+};
+
+// Kernel arguments passed by value next to the PassParams pointer: what a wave needs before anything else, so that its
+// first dependent loads (draw table, bin counter -> bin records) hang off the kernarg load, not off a second memory hop.
+struct GeometryHead { const DrawDesc* draws; uint32_t num_draws; };
+struct RasterHead {
+    uint32_t* bin_count; const TileRec* bin_recs; uint32_t* big_count;
+    uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;
 };
 
 }  // namespace mirhi

@@ -18,6 +18,7 @@
 // binary32 {+,-,*,/} in the order fixed by DESIGN.md "Pipeline specification"; this file is
 // compiled with -ffp-contract=off so results are bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "mirhi_device.h"
@@ -57,6 +58,10 @@ __device__ __forceinline__ CBytePtr cb(const uint8_t* p) { return (CBytePtr)(uin
 __device__ __forceinline__ float ldcf(CBytePtr p, uint32_t off) { return *reinterpret_cast<const MIRHI_CONST float*>(p + off); }
 __device__ __forceinline__ uint32_t ldcu(CBytePtr p, uint32_t off) { return *reinterpret_cast<const MIRHI_CONST uint32_t*>(p + off); }
 typedef const MIRHI_CONST DrawDesc& DrawRef;
+typedef const MIRHI_CONST PassParams* ParamsPtr;
+typedef const MIRHI_CONST PassParams& ParamsRef;   // scalar (s_load) access to the pass parameters in device memory
+// opaque to the optimiser: loads through the result cannot be hoisted above this point
+__device__ __forceinline__ ParamsPtr launder_params(ParamsPtr p) { asm volatile("" : "+s"(p)); return p; }
 
 // HLSL mul(M, v), M column-major (vertex/model.hlsl:44,48); accumulation order = oracle's.
 __device__ __forceinline__ f4 mat4_mul(CFloatPtr m, f4 v) {
@@ -129,7 +134,7 @@ __device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
 // ------------------------------------------------------------------------------------------------
 // a5: clip-space triangle (all w > 0) -> snapped, culled, oriented screen triangle + depth plane
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool setup_triangle(const PassParams& P, DrawRef D, const f4 c[3], uint32_t prim,
+__device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 c[3], uint32_t prim,
                                                ScreenTri& t) {
     float z[3];
 #pragma unroll
@@ -180,7 +185,7 @@ __device__ __forceinline__ bool setup_triangle(const PassParams& P, DrawRef D, c
     return true;
 }
 
-__device__ __forceinline__ void emit_big(const PassParams& P, const ScreenTri& t) {
+__device__ __forceinline__ void emit_big(ParamsRef P, const ScreenTri& t) {
     const uint32_t slot = atomicAdd(P.big_count, 1u);
     if (slot < P.big_cap) store_tri(reinterpret_cast<uint4*>(P.big_recs) + (size_t)slot * 3u, t);
     else __hip_atomic_fetch_or(P.status, STATUS_BIG_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -190,7 +195,7 @@ __device__ __forceinline__ void emit_big(const PassParams& P, const ScreenTri& t
 // copies the triangle record into the bin of each of the <= 4x4 tiles it overlaps.  All returning
 // atomics are issued before the first result is consumed; when every active lane of a slot targets
 // the same tile (the common case for meshes) one lane reserves the whole range.
-__device__ __forceinline__ void bin_triangle(const PassParams& P, bool valid, const ScreenTri& t) {
+__device__ __forceinline__ void bin_triangle(ParamsRef P, bool valid, const ScreenTri& t) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
@@ -284,7 +289,7 @@ __device__ __forceinline__ uint32_t outcode_view(f4 c) {
 constexpr int CLIP_MAX_VERTS = 10;     // 3 + one per plane (near, far, 4 guard-band planes) = 9
 constexpr int CLIP_BATCH = 8;          // lanes clipping concurrently per wave (LDS polygon slots)
 
-__device__ __forceinline__ void clip_and_emit(const PassParams& P, DrawRef D, f4 (*poly)[CLIP_MAX_VERTS],
+__device__ __forceinline__ void clip_and_emit(ParamsRef P, DrawRef D, f4 (*poly)[CLIP_MAX_VERTS],
                                               f4 c0, f4 c1, f4 c2, uint32_t any, uint32_t prim) {
     f4* in = poly[0]; f4* tmp = poly[1];
     in[0] = c0; in[1] = c1; in[2] = c2;
@@ -314,7 +319,7 @@ __device__ __forceinline__ void clip_and_emit(const PassParams& P, DrawRef D, f4
     }
 }
 
-__device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim) {
+__device__ __forceinline__ uint32_t find_draw(ParamsRef P, uint32_t prim) {
     uint32_t lo = 0, hi = P.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -326,7 +331,8 @@ __device__ __forceinline__ uint32_t find_draw(const PassParams& P, uint32_t prim
 // ------------------------------------------------------------------------------------------------
 // a4: vertex-shader pre-pass for the MODEL / MODEL_FULL programs (vertex/model.hlsl:39-68)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams P) {
+__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* __restrict__ params) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     const MIRHI_CONST VsJob* jobs = (const MIRHI_CONST VsJob*)(uintptr_t)P.vs_jobs;
     uint32_t lo = 0, hi = P.num_vs_jobs;
@@ -361,19 +367,52 @@ __global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams P
 
 __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
 
-// one wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
-// and pipeline-state word) is wave-uniform and lives in SGPRs
-__global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams P) {
+// Slot-parallel binning for the wide geometry variant: the 16 lanes of a triangle's group each own one of the (up to
+// 4x4) tiles it overlaps -- one atomic and one record copy per lane, no loop.  Same bins, same big-list rule.
+__device__ __forceinline__ void bin_triangle_wide(ParamsRef P, bool valid, const ScreenTri& t, uint32_t k, bool lead) {
+    int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
+    bool spill = false;
+    if (valid) {
+        tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
+        ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
+        nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
+        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
+    }
+    const int32_t kx = (int32_t)(k % MAX_BIN_SPAN), ky = (int32_t)(k / MAX_BIN_SPAN);
+    const bool has = valid && !spill && kx < ntx && ky < nty;
+    bool full = false;
+    if (has) {
+        const uint32_t tile = (uint32_t)(ty0 + ky - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)(tx0 + kx);
+        const uint32_t slot = atomicAdd(&P.bin_count[tile], 1u);
+        if (slot < P.bin_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
+        else full = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
+    }
+    const uint32_t g = (threadIdx.x & 63u) >> 4;
+    const uint32_t group_full = (uint32_t)(__ballot(full) >> (16u * g)) & 0xFFFFu;
+    if (lead && valid && (spill || group_full)) emit_big(P, t);
+}
+
+// One wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
+// and pipeline-state word) is wave-uniform and lives in SGPRs.
+//   WIDE = 0: one lane per triangle (64 triangles per wave), the lane walks its <= 16 bins.
+//   WIDE = 1: sixteen lanes per triangle (4 triangles per wave), one bin per lane.  For small scopes the kernel is
+//             bound by the latency of ONE wave's instruction stream (10k triangles are 157 waves on 1024 SIMDs); this
+//             variant makes that stream ~5x shorter and the launch 16x wider.  The host picks it by triangle count.
+template <int WIDE>
+__global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ f4 poly[CLIP_BATCH][2][CLIP_MAX_VERTS];   // 2.5 KB: clipping lanes take turns, 8 at a time
     GSTAMP(0);
-    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
-    uint32_t lo = 0, hi = P.num_draws;
+    const uint32_t slot0 = blockIdx.x * (WIDE ? GEOM_THREADS / 16u : GEOM_THREADS);
+    uint32_t lo = 0, hi = H.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (const_draws(P.draws)[mid].slot_base <= slot0) lo = mid; else hi = mid;
+        if (const_draws(H.draws)[mid].slot_base <= slot0) lo = mid; else hi = mid;
     }
-    DrawRef D = const_draws(P.draws)[lo];
-    const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
+    DrawRef D = const_draws(H.draws)[lo];
+    const uint32_t sub = WIDE ? (threadIdx.x & 15u) : 0u;          // bin owned by this lane (WIDE)
+    const bool lead = sub == 0u;                                     // the lane that does a triangle's once-only work
+    const uint32_t tri = slot0 - D.slot_base + (WIDE ? threadIdx.x >> 4 : threadIdx.x);
     const uint32_t prim = D.prim_base + tri;
     bool valid = false;
     uint32_t any = 0;
@@ -411,7 +450,7 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             if (any == 0) valid = setup_triangle(P, D, c, prim, t);
         }
     }
-    if (P.flat_color && D.program == 0 && (valid || any)) {
+    if (P.flat_color && D.program == 0 && (valid || any) && lead) {
         // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
         const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
         const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
@@ -421,8 +460,10 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
         P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
     }
     GSTAMP(1);
-    bin_triangle(P, valid, t);
+    if (WIDE) bin_triangle_wide(P, valid, t, sub, lead);
+    else bin_triangle(P, valid, t);
     GSTAMP(2);
+    if (!lead) any = 0;                              // (WIDE) one lane per triangle clips
     uint64_t todo = __ballot(any != 0);
     while (todo) {                                   // rare: triangles crossing the near / far / guard planes
         const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << (threadIdx.x & 63u)) - 1ull));
@@ -871,7 +912,7 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
 // KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied).
 template <int KEYED, bool BOXED>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
-                                              float fiy0, const PassParams& P, PixelState& st, uint32_t qbit0) {
+                                              float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
     const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
     const int32_t B0 = (int32_t)r.w1.z, B1 = (int32_t)r.w1.w, B2 = (int32_t)r.w2.x;
     const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
@@ -912,7 +953,7 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
 // wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
 template <int KEYED, int TP>
 __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
-                                             int32_t ix0, int32_t iy0, float fix0, float fiy0, const PassParams& P,
+                                             int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
                                              PixelState& st, uint32_t qbit0, uint32_t lane) {
     for (uint32_t g = 0; g < n; g += 64u) {
         const uint32_t j = g + lane;
@@ -942,7 +983,7 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
 // triangles this keeps all 64 lanes busy on different triangles, where the pixel-parallel loop above would spend a
 // full wave iteration per triangle with a handful of lanes covered.  Same integers, same depth FMAs, same keys.
 template <int KEYED>
-__device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, unsigned long long* lds_key, const PassParams& P) {
+__device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, unsigned long long* lds_key, ParamsRef P) {
     const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
     const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
     const float dxt = __uint_as_float(rec[2].y), dyt = __uint_as_float(rec[2].z), z0 = __uint_as_float(rec[2].w);
@@ -970,7 +1011,7 @@ __device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, u
     }
 }
 
-__device__ __forceinline__ void init_key(const PassParams& P, uint32_t px, uint32_t py, bool valid, uint32_t& zk,
+__device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, bool valid, uint32_t& zk,
                                          uint32_t& idk, uint32_t& zorig) {
     zk = P.init_zk; idk = P.init_idk; zorig = P.clear_depth_bits;
     if (P.depth_load && P.depth && valid) {
@@ -991,16 +1032,19 @@ template <int KEYED, int TP>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
-                                            const PassParams& P, PixelState& st, uint32_t qbit0, uint32_t tid,
+                                            ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
                                             uint32_t lane) {
     const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
+    // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
+    // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
+    const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
     for (uint32_t base = 0; base < n_total; base += RASTER_CHUNK) {
         if (tid == 0) *lds_count = 0;
         __syncthreads();
-        const uint32_t i = base + tid;
+        const uint32_t i = base + ftid;
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
-        if (tid < RASTER_CHUNK && i < n_total) {
+        if (ftid < RASTER_CHUNK && i < n_total) {
             // all three words are requested together: one memory round trip, not two (a bin holds only records whose
             // box overlaps the tile, so the box test below almost never saves the first two loads)
             const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
@@ -1047,24 +1091,29 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 : 8)) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams P) {
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 : 8)) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
     __shared__ uint32_t lds_count;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, each XCD
-    // has its own L2).  Runs of G consecutive tiles go to the same XCD so neighbouring tiles -- which share triangle
-    // records, shaded vertices and texture footprints -- hit the same L2, while the runs stay interleaved across
-    // XCDs for load balance (one contiguous band per XCD measured 20-30 % slower on unevenly covered frames).
-    const uint32_t G = P.xcd_swizzle, ntiles = gridDim.x;
-    uint32_t tile = blockIdx.x;
-    if (G > 1u && ntiles % (8u * G) == 0u) {
-        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        tile = ((j / G) * 8u + xcd) * G + (j % G);
+    // (one contiguous band of tiles per XCD measured 20-30 % slower on unevenly covered frames: runs stay interleaved)
+    // Plain order: a 2-D grid, (blockIdx.x, blockIdx.y) = (tile column, tile row of the band): no division.
+    // P.xcd_swizzle > 1 (1-D grid): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, each XCD
+    // has its own L2); runs of G consecutive tiles go to the same XCD so neighbouring tiles hit the same L2.
+    uint32_t tx = blockIdx.x, tyr = blockIdx.y;
+    if (gridDim.y == 1u && P.xcd_swizzle > 1u) {
+        const uint32_t G = P.xcd_swizzle, ntiles = gridDim.x;
+        uint32_t t = blockIdx.x;
+        if (ntiles % (8u * G) == 0u) {
+            const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+            t = ((j / G) * 8u + xcd) * G + (j % G);
+        }
+        tx = t % H.tiles_x; tyr = t / H.tiles_x;
     }
-    const uint32_t tx = tile % P.tiles_x, ty = P.tile_row_begin + tile / P.tiles_x;
+    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
     const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
     const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
     const float fix0 = (float)ix0, fiy0 = (float)iy0;
@@ -1074,34 +1123,42 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
 
     STAMP(0);
     // both counters are fetched up front so their latencies overlap
-    const uint32_t count_raw = P.bin_count[tile];
-    const uint32_t nbig_raw = *P.big_count;
-    const uint32_t count = count_raw < P.bin_cap ? count_raw : P.bin_cap;
-    const uint32_t nbig = nbig_raw < P.big_cap ? nbig_raw : P.big_cap;
+    // (the head of the parameters comes by value: the counter loads depend on the kernarg load alone, not on a second hop)
+    const uint32_t count_raw = H.bin_count[tile];
+    const uint32_t nbig_raw = *H.big_count;
+    const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
+    const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
 
     if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
     PixelState st;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
-        uint32_t zo;
-        init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
+    for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
+    if (P.depth_load && P.depth) {              // second scope on a kept depth buffer: keys start from the stored depth
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+            uint32_t zo;
+            init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
+        }
     }
 
     STAMP(1);
     if (count) {
-        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(P.bin_recs) + (size_t)tile * P.bin_cap * 3u, count, lds_rec, lds_box,
+        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u, count, lds_rec, lds_box,
                            &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
-        if (tid == 0) P.bin_count[tile] = 0;            // ready for the next scope that uses this workspace
     }
     STAMP(2);
-    if (tile == 0 && tid == 0) {
-        *P.big_count_next = 0;                          // the next scope on this workspace appends to the other counter
-        P.status[1] = nbig_raw;
+    {   // parameters of this phase are (re)read here, see launder_params
+        const ParamsPtr B = launder_params((ParamsPtr)(uintptr_t)params);
+        if (count && tid == 0) B->bin_count[tile] = 0;  // ready for the next scope that uses this workspace
+        if (tile == 0 && tid == 0) {
+            *B->big_count_next = 0;                     // the next scope on this workspace appends to the other counter
+            B->status[1] = nbig_raw;
+        }
+        if (nbig)    // every tile tests every large / clipped / spilled triangle
+            raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(B->big_recs), nbig, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask,
+                               ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
     }
-    if (nbig)    // every tile tests every large / clipped / spilled triangle
-        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(P.big_recs), nbig, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0,
-                           iy0, fix0, fiy0, P, st, qbit0, tid, lane);
 
     STAMP(3);
     if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
@@ -1116,36 +1173,44 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
             st.zk[b] = (uint32_t)(kmin >> 32); st.idk[b] = (uint32_t)kmin;
         }
     }
+    // The resolve reads its parameters through a laundered kernarg pointer: the scalar loads are issued here, not at
+    // kernel entry, so their registers are not live across the raster loops (which otherwise spill SGPRs to VGPR lanes).
+    const ParamsPtr R = launder_params((ParamsPtr)(uintptr_t)params);
     // flat colours of all four owned pixels are requested before the first one is used (four overlapping loads
     // instead of four dependent round trips in the loop below)
     uint32_t flat4[4] = {0u, 0u, 0u, 0u};
-    if (PROGS == 1 && P.flat_color && !P.depth_load) {
+    const uint32_t* flat_color = PROGS == 1 && !R->depth_load ? R->flat_color : nullptr;
+    const uint32_t init_zk = R->init_zk, init_idk = R->init_idk;
+    if (flat_color) {
+        const uint32_t idflip = R->idflip;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const bool won = !(st.zk[b] == P.init_zk && st.idk[b] == P.init_idk);
-            if (won) flat4[b] = P.flat_color[P.idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b]];
+            const bool won = !(st.zk[b] == init_zk && st.idk[b] == init_idk);
+            if (won) flat4[b] = flat_color[idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b]];
         }
     }
     // Fast exit for the headline shape of work: every covered pixel of this wave belongs to a flat-coloured
     // triangle whose packed colour the geometry kernel already produced, and only the 8-bit colour target is
     // written.  Same values as the general loop below, a fraction of its instructions.
-    if (PROGS == 1 && P.flat_color && !P.depth_load && P.color_format != 2 && !P.prim_out && !(P.depth && P.depth_store)) {
+    if (flat_color && R->color_format != 2 && !R->prim_out && !(R->depth && R->depth_store)) {
         bool need_shade = false;
         uint32_t outc[4]; bool won4[4];
+        const uint32_t clear_packed = R->clear_packed;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            won4[b] = !(st.zk[b] == P.init_zk && st.idk[b] == P.init_idk);
+            won4[b] = !(st.zk[b] == init_zk && st.idk[b] == init_idk);
             need_shade = need_shade || (won4[b] && flat4[b] == 0u);
-            outc[b] = won4[b] ? flat4[b] : P.clear_packed;
+            outc[b] = won4[b] ? flat4[b] : clear_packed;
         }
         if (__ballot(need_shade) == 0ull) {
-            const bool whole = (tx + 1u) * TILE <= P.width && (ty + 1u) * TILE <= P.height;     // wave-uniform
-            uint32_t* dst = reinterpret_cast<uint32_t*>(P.color) + (size_t)py0 * P.width + px0;
+            const uint32_t width = R->width, height = R->height, color_load = R->color_load;
+            const bool whole = (tx + 1u) * TILE <= width && (ty + 1u) * TILE <= height;     // wave-uniform
+            uint32_t* dst = reinterpret_cast<uint32_t*>(R->color) + (size_t)py0 * width + px0;
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
-                const bool inb = whole || (px < P.width && py < P.height);
-                if (inb && (won4[b] || !P.color_load)) dst[(size_t)(b >> 1) * BLOCK * P.width + (size_t)(b & 1) * BLOCK] = outc[b];
+                const bool inb = whole || (px < width && py < height);
+                if (inb && (won4[b] || !color_load)) dst[(size_t)(b >> 1) * BLOCK * width + (size_t)(b & 1) * BLOCK] = outc[b];
             }
             STAMP(4);
             return;
@@ -1203,36 +1268,41 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_vertex(const PassParams& P, hipStream_t stream) {
+hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream) {
     if (P.vs_total_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), 0, stream, P);
+    hipLaunchKernelGGL(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), 0, stream, dev_params);
     return hipGetLastError();
 }
 
-hipError_t launch_geometry(const PassParams& P, hipStream_t stream) {
+hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream) {
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t blocks = P.total_slots / GEOM_THREADS;
-    hipLaunchKernelGGL(geometry_kernel, dim3(blocks), dim3(GEOM_THREADS), 0, stream, P);
+    const GeometryHead H = {P.draws, P.num_draws};
+    // small scopes: sixteen lanes per triangle (see geometry_kernel); MIRHI_GEOM_WIDE_MAX overrides the threshold
+    static const uint32_t wide_max = [] { const char* e = getenv("MIRHI_GEOM_WIDE_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : GEOM_WIDE_MAX_SLOTS; }();
+    if (P.total_slots <= wide_max) hipLaunchKernelGGL(geometry_kernel<1>, dim3(blocks * 16u), dim3(GEOM_THREADS), 0, stream, dev_params, H);
+    else hipLaunchKernelGGL(geometry_kernel<0>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
     return hipGetLastError();
 }
 
 template <int KEYED, int TP>
-static void launch_raster_k(const PassParams& P, uint32_t programs, dim3 grid, hipStream_t stream) {
+static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream) {
     const dim3 block(RASTER_THREADS);
-    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P);
-    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P);
-    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel<4, KEYED, TP>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((raster_kernel<1, KEYED, TP>), grid, block, 0, stream, P);
+    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P, H);
+    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P, H);
+    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel<4, KEYED, TP>), grid, block, 0, stream, P, H);
+    else hipLaunchKernelGGL((raster_kernel<1, KEYED, TP>), grid, block, 0, stream, P, H);
 }
 
-hipError_t launch_raster(const PassParams& P, uint32_t programs, hipStream_t stream) {
+hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
-    const dim3 grid(P.tiles_x * rows);
+    const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
-    if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(P, programs, grid, stream); else launch_raster_k<1, 1>(P, programs, grid, stream); }
-    else { if (plain) launch_raster_k<0, 0>(P, programs, grid, stream); else launch_raster_k<1, 0>(P, programs, grid, stream); }
+    const RasterHead H = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap};
+    if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream); }
+    else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream); }
     return hipGetLastError();
 }
 
