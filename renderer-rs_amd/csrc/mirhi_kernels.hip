@@ -910,6 +910,13 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
 // KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied).
+// d = (a << 3) + b in one instruction (8 = BLOCK: the step of an edge function from one 8x8 block to the next)
+__device__ __forceinline__ int32_t step8(int32_t a, int32_t b) {
+    int32_t d;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int KEYED, bool BOXED>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
                                               float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
@@ -927,23 +934,32 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
     for (int b = 0; b < 4; b++) {
         const int bx = b & 1, by = b >> 1;
         if (!(m & (qbit0 << (by * 4 + bx)))) continue;
-        const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK;
-        const int32_t S1 = s1 + (A1 * bx + B1 * by) * BLOCK;
-        const int32_t S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
-        bool inside = (S0 | S1 | S2) >= 0;
-        if (BOXED) {
-            const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
-            inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
-                     iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
-        }
+        // edge functions at this block: one shift-add per edge and step (v_lshl_add_u32), no shared shift results
+        int32_t sgn;                                         // covered <=> sign bit clear
+        if (!bx && !by) sgn = s0 | s1 | s2;
+        else if (bx && !by) sgn = step8(A0, s0) | step8(A1, s1) | step8(A2, s2);
+        else if (!bx && by) sgn = step8(B0, s0) | step8(B1, s1) | step8(B2, s2);
+        else sgn = step8(B0, step8(A0, s0)) | step8(B1, step8(A1, s1)) | step8(B2, step8(A2, s2));
         const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
         const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
         // clamp to [0,1]: v_med3_f32 returns min3 = 0 when z is NaN; the mask turns a -0 result into +0
         uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
-        if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
-        const uint64_t key = ((uint64_t)zk << 32) | idk;
-        const uint64_t cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
-        const bool upd = inside && key < cur;
+        bool upd;
+        if (!KEYED && !BOXED) {
+            // plain key: depth bits are <= 0x3F800000, so a lane outside the triangle can carry its miss in the key's
+            // top bit (such a key never beats a stored one) -- no separate compare, no mask AND
+            zk |= (uint32_t)sgn & 0x80000000u;             // (an updating lane has the bit clear: zk is stored unchanged)
+            upd = (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+        } else {
+            bool inside = sgn >= 0;
+            if (BOXED) {
+                const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
+                inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
+                         iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
+            }
+            if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+            upd = inside && (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+        }
         st.zk[b] = upd ? zk : st.zk[b];
         st.idk[b] = upd ? idk : st.idk[b];
     }
@@ -1091,7 +1107,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 : 8)) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
@@ -1115,7 +1131,6 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
     }
     const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
     const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
-    const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
     const float fix0 = (float)ix0, fiy0 = (float)iy0;
     // the four 8x8 blocks of quadrant q are bits (2*(q>>1)+by)*4 + 2*(q&1)+bx of the record's block mask
     const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
@@ -1134,6 +1149,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
 #pragma unroll
     for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
     if (P.depth_load && P.depth) {              // second scope on a kept depth buffer: keys start from the stored depth
+        const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
@@ -1143,21 +1159,26 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
     }
 
     STAMP(1);
-    if (count) {
-        raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u, count, lds_rec, lds_box,
-                           &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
-    }
-    STAMP(2);
-    {   // parameters of this phase are (re)read here, see launder_params
-        const ParamsPtr B = launder_params((ParamsPtr)(uintptr_t)params);
-        if (count && tid == 0) B->bin_count[tile] = 0;  // ready for the next scope that uses this workspace
-        if (tile == 0 && tid == 0) {
-            *B->big_count_next = 0;                     // the next scope on this workspace appends to the other counter
-            B->status[1] = nbig_raw;
+    // the tile's bin, then the list every tile tests (large / clipped / spilled triangles): one copy of the code
+    const uint4* list = reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u;
+    uint32_t n_list = count;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (n_list) raster_list<KEYED, TP>(list, n_list, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+                                           qbit0, tid, lane);
+        if (pass == 0) {
+            STAMP(2);
+            // parameters of this phase are (re)read here, see launder_params
+            const ParamsPtr B = launder_params((ParamsPtr)(uintptr_t)params);
+            if (count && tid == 0) B->bin_count[tile] = 0;  // ready for the next scope that uses this workspace
+            if (tile == 0 && tid == 0) {
+                *B->big_count_next = 0;                     // the next scope on this workspace appends to the other counter
+                B->status[1] = nbig_raw;
+            }
+            if (!nbig) break;
+            list = reinterpret_cast<const uint4*>(B->big_recs);
+            n_list = nbig;
         }
-        if (nbig)    // every tile tests every large / clipped / spilled triangle
-            raster_list<KEYED, TP>(reinterpret_cast<const uint4*>(B->big_recs), nbig, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask,
-                               ix0, iy0, fix0, fiy0, P, st, qbit0, tid, lane);
     }
 
     STAMP(3);
@@ -1176,6 +1197,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (KEYED ? 6 : (TP ? 7 
     // The resolve reads its parameters through a laundered kernarg pointer: the scalar loads are issued here, not at
     // kernel entry, so their registers are not live across the raster loops (which otherwise spill SGPRs to VGPR lanes).
     const ParamsPtr R = launder_params((ParamsPtr)(uintptr_t)params);
+    const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
     // flat colours of all four owned pixels are requested before the first one is used (four overlapping loads
     // instead of four dependent round trips in the loop below)
     uint32_t flat4[4] = {0u, 0u, 0u, 0u};
