@@ -23,7 +23,6 @@ constexpr int MAX_BIN_SPAN = 4;       // triangles spanning more than 4x4 tiles 
 constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay inside +-2^22 sub-pixels
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t MAX_PRIM_ID = 0xFFFFFFFDu;
-constexpr uint32_t GEOM_WIDE_MAX_SLOTS = 65536u;   // scopes up to this many (padded) triangles use the 16-lanes-per-triangle geometry kernel
 
 enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u };
 

@@ -191,69 +191,6 @@ __device__ __forceinline__ void emit_big(ParamsRef P, const ScreenTri& t) {
     else __hip_atomic_fetch_or(P.status, STATUS_BIG_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Convergent (every lane of the wave calls it, `valid` says whether the lane holds a triangle):
-// copies the triangle record into the bin of each of the <= 4x4 tiles it overlaps.  All returning
-// atomics are issued before the first result is consumed; when every active lane of a slot targets
-// the same tile (the common case for meshes) one lane reserves the whole range.
-__device__ __forceinline__ void bin_triangle(ParamsRef P, bool valid, const ScreenTri& t) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lt = (1ull << lane) - 1ull;
-    int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
-    bool spill = false;
-    if (valid) {
-        tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
-        ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
-        nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
-        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
-    }
-    const bool binned = valid && !spill;
-    const uint32_t tile0 = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
-    // Phase 1: reserve a slot in every overlapped tile's bin.  No result is consumed in this phase, so all
-    // atomics of a lane are in flight together.  If the wave's triangles are spatially coherent (mesh order:
-    // many lanes hit the same tile), lanes targeting the same tile are grouped and the group's first lane reserves
-    // the whole range with ONE returning atomic (up to GROUP_ROUNDS distinct tiles per slot).  Grouping stops at the
-    // first single-lane group (incoherent input such as random triangles would only serialise its atomics);
-    // the remaining lanes reserve individually.
-    constexpr int NSLOT = MAX_BIN_SPAN * MAX_BIN_SPAN, GROUP_ROUNDS = 8, GROUP_MIN = 2;
-    uint32_t raw[NSLOT];       // atomic result (held by the reserving lane)
-    uint32_t who[NSLOT];       // reserving lane | rank within its group << 8
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-        const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
-        const bool has = binned && kx < ntx && ky < nty;
-        const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
-        raw[k] = 0; who[k] = lane;
-        uint64_t rem = __ballot(has);
-        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-            const uint64_t grp = __ballot(has && tile == t0) & rem;
-            if (__popcll(grp) < GROUP_MIN) break;               // incoherent: fall through to individual atomics
-            if (has && tile == t0 && ((rem >> lane) & 1ull)) who[k] = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
-            if ((int)lane == leader) raw[k] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
-            rem &= ~grp;
-        }
-        if (has && ((rem >> lane) & 1ull)) raw[k] = atomicAdd(&P.bin_count[tile], 1u);   // ungrouped lanes
-    }
-    // Phase 2: copy the record into each reserved slot
-#pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
-        const int kx = k % MAX_BIN_SPAN, ky = k / MAX_BIN_SPAN;
-        const bool has = binned && kx < ntx && ky < nty;
-        if (!__ballot(has)) continue;
-        const uint32_t slot = (uint32_t)__shfl((int)raw[k], (int)(who[k] & 0xFFu)) + (who[k] >> 8);
-        if (has) {
-            if (slot < P.bin_cap) {
-                const uint32_t tile = tile0 + (uint32_t)ky * P.tiles_x + (uint32_t)kx;
-                store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
-            } else {
-                spill = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
-            }
-        }
-    }
-    if (valid && spill) emit_big(P, t);
-}
-
 // clip planes: near z>=0, far w-z>=0, guard band x,y within +-g*w (oracle: clip_polygon)
 __device__ __forceinline__ float plane_dist(int plane, f4 c, float gx, float gy) {
     switch (plane) {
@@ -367,9 +304,15 @@ __global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* 
 
 __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
 
-// Slot-parallel binning for the wide geometry variant: the 16 lanes of a triangle's group each own one of the (up to
-// 4x4) tiles it overlaps -- one atomic and one record copy per lane, no loop.  Same bins, same big-list rule.
-__device__ __forceinline__ void bin_triangle_wide(ParamsRef P, bool valid, const ScreenTri& t, uint32_t k, bool lead) {
+// Pair-parallel binning: the wave's (triangle, bin) pairs -- one per triangle for fine meshes, about five for scattered
+// 50-pixel triangles, sixteen at most -- are enumerated densely through LDS and dealt to the lanes 64 at a time, one
+// record copy per pair.  Every lane stays busy; a lane walking its own <= 16 bins (the first design) issued 2-3x the
+// instructions per wave, and sixteen lanes per triangle 10x (measured: C2 907 / 987 / 1089 Mtris/s for walk / wide / pairs).
+constexpr uint32_t PAIR_MAX = GEOM_THREADS * MAX_BIN_SPAN * MAX_BIN_SPAN;
+__device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
+                                                   uint32_t* lds_meta, uint16_t* lds_owner) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt = (1ull << lane) - 1ull;
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
     bool spill = false;
     if (valid) {
@@ -378,41 +321,98 @@ __device__ __forceinline__ void bin_triangle_wide(ParamsRef P, bool valid, const
         nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
         spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
     }
-    const int32_t kx = (int32_t)(k % MAX_BIN_SPAN), ky = (int32_t)(k / MAX_BIN_SPAN);
-    const bool has = valid && !spill && kx < ntx && ky < nty;
-    bool full = false;
-    if (has) {
-        const uint32_t tile = (uint32_t)(ty0 + ky - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)(tx0 + kx);
-        const uint32_t slot = atomicAdd(&P.bin_count[tile], 1u);
-        if (slot < P.bin_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
-        else full = true;        // bin full: the triangle also goes to the big list (idempotent resolve)
+    const bool binned = valid && !spill;
+    const uint32_t nb = binned ? (uint32_t)(ntx * nty) : 0u;
+    // exclusive prefix sum of nb (<= 16) over the wave from five bit planes of ballots
+    uint32_t ex = 0, total = 0;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 5; bit++) {
+        const uint64_t m = __ballot(((nb >> bit) & 1u) != 0u);
+        ex += (uint32_t)__popcll(m & lt) << bit;
+        total += (uint32_t)__popcll(m) << bit;
     }
-    const uint32_t g = (threadIdx.x & 63u) >> 4;
-    const uint32_t group_full = (uint32_t)(__ballot(full) >> (16u * g)) & 0xFFFFu;
-    if (lead && valid && (spill || group_full)) emit_big(P, t);
+    if (binned) {
+        lds_tri[lane][0] = make_uint4((uint32_t)t.X[0], (uint32_t)t.Y[0], (uint32_t)t.X[1], (uint32_t)t.Y[1]);
+        lds_tri[lane][1] = make_uint4((uint32_t)t.X[2], (uint32_t)t.Y[2], __float_as_uint(t.z0), __float_as_uint(t.zx));
+        lds_tri[lane][2] = make_uint4(__float_as_uint(t.zy), t.idk, (uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.boxed << 31),
+                                      (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
+        lds_meta[lane] = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+        uint32_t pos = ex;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)(MAX_BIN_SPAN * MAX_BIN_SPAN); k++) {
+            if ((int32_t)(k % MAX_BIN_SPAN) < ntx && (int32_t)(k / MAX_BIN_SPAN) < nty) lds_owner[pos++] = (uint16_t)(lane | (k << 8));
+        }
+    }
+    __syncthreads();            // one wave per workgroup: orders the LDS writes above before the reads below
+    // All returning atomics of the wave are issued before the first result is consumed.  Lanes of a round that target
+    // the same tile (mesh order: most of them) are grouped and the group's first lane reserves the whole range with one
+    // atomic; grouping stops at the first small group (scattered input would only serialise its atomics).
+    constexpr uint32_t ROUNDS = PAIR_MAX / GEOM_THREADS;
+    constexpr int GROUP_ROUNDS = 8, GROUP_MIN = 2;
+    uint32_t raw[ROUNDS];      // atomic result (held by the reserving lane)
+    uint32_t who[ROUNDS];      // reserving lane | rank within its group << 8
+#pragma unroll
+    for (uint32_t it = 0; it < ROUNDS; it++) {
+        raw[it] = 0; who[it] = lane;
+        if (it * GEOM_THREADS >= total) break;
+        const uint32_t p = it * GEOM_THREADS + lane;
+        const bool act = p < total;
+        uint32_t tile = 0;
+        if (act) {
+            const uint32_t o = lds_owner[p], kk = o >> 8;
+            tile = lds_meta[o & 0xFFu] + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);   // (flag bit not set yet)
+        }
+        uint64_t rem = __ballot(act);
+        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+            const uint64_t grp = __ballot(act && tile == t0) & rem;
+            if (__popcll(grp) < GROUP_MIN) break;
+            if (act && tile == t0 && ((rem >> lane) & 1ull)) who[it] = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
+            if ((int)lane == leader) raw[it] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
+            rem &= ~grp;
+        }
+        if (act && ((rem >> lane) & 1ull)) raw[it] = atomicAdd(&P.bin_count[tile], 1u);   // ungrouped lanes
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < ROUNDS; it++) {
+        if (it * GEOM_THREADS >= total) break;
+        const uint32_t p = it * GEOM_THREADS + lane;
+        const uint32_t slot = (uint32_t)__shfl((int)raw[it], (int)(who[it] & 0xFFu)) + (who[it] >> 8);
+        if (p < total) {
+            const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
+            const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
+            if (slot < P.bin_cap) {
+                uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u;
+                dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
+            } else {
+                atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once
+            }
+        }
+    }
+    __syncthreads();
+    if (binned && (lds_meta[lane] >> 31)) spill = true;    // (idempotent resolve: being in some bins as well is harmless)
+    if (valid && spill) emit_big(P, t);
 }
 
 // One wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
-// and pipeline-state word) is wave-uniform and lives in SGPRs.
-//   WIDE = 0: one lane per triangle (64 triangles per wave), the lane walks its <= 16 bins.
-//   WIDE = 1: sixteen lanes per triangle (4 triangles per wave), one bin per lane.  For small scopes the kernel is
-//             bound by the latency of ONE wave's instruction stream (10k triangles are 157 waves on 1024 SIMDs); this
-//             variant makes that stream ~5x shorter and the launch 16x wider.  The host picks it by triangle count.
-template <int WIDE>
+// and pipeline-state word) is wave-uniform and lives in SGPRs.  One lane per triangle up to the screen-space setup,
+// then bin_triangle_pairs.
 __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ f4 poly[CLIP_BATCH][2][CLIP_MAX_VERTS];   // 2.5 KB: clipping lanes take turns, 8 at a time
+    __shared__ uint4 lds_tri[GEOM_THREADS][3];
+    __shared__ uint32_t lds_meta[GEOM_THREADS];
+    __shared__ uint16_t lds_owner[PAIR_MAX];
     GSTAMP(0);
-    const uint32_t slot0 = blockIdx.x * (WIDE ? GEOM_THREADS / 16u : GEOM_THREADS);
+    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     uint32_t lo = 0, hi = H.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (const_draws(H.draws)[mid].slot_base <= slot0) lo = mid; else hi = mid;
     }
     DrawRef D = const_draws(H.draws)[lo];
-    const uint32_t sub = WIDE ? (threadIdx.x & 15u) : 0u;          // bin owned by this lane (WIDE)
-    const bool lead = sub == 0u;                                     // the lane that does a triangle's once-only work
-    const uint32_t tri = slot0 - D.slot_base + (WIDE ? threadIdx.x >> 4 : threadIdx.x);
+    const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
     const uint32_t prim = D.prim_base + tri;
     bool valid = false;
     uint32_t any = 0;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             if (any == 0) valid = setup_triangle(P, D, c, prim, t);
         }
     }
-    if (P.flat_color && D.program == 0 && (valid || any) && lead) {
+    if (P.flat_color && D.program == 0 && (valid || any)) {
         // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
         const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
         const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
@@ -460,10 +460,8 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
         P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
     }
     GSTAMP(1);
-    if (WIDE) bin_triangle_wide(P, valid, t, sub, lead);
-    else bin_triangle(P, valid, t);
+    bin_triangle_pairs(P, valid, t, lds_tri, lds_meta, lds_owner);
     GSTAMP(2);
-    if (!lead) any = 0;                              // (WIDE) one lane per triangle clips
     uint64_t todo = __ballot(any != 0);
     while (todo) {                                   // rare: triangles crossing the near / far / guard planes
         const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << (threadIdx.x & 63u)) - 1ull));
@@ -1300,10 +1298,7 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t blocks = P.total_slots / GEOM_THREADS;
     const GeometryHead H = {P.draws, P.num_draws};
-    // small scopes: sixteen lanes per triangle (see geometry_kernel); MIRHI_GEOM_WIDE_MAX overrides the threshold
-    static const uint32_t wide_max = [] { const char* e = getenv("MIRHI_GEOM_WIDE_MAX"); return e ? (uint32_t)strtoul(e, nullptr, 10) : GEOM_WIDE_MAX_SLOTS; }();
-    if (P.total_slots <= wide_max) hipLaunchKernelGGL(geometry_kernel<1>, dim3(blocks * 16u), dim3(GEOM_THREADS), 0, stream, dev_params, H);
-    else hipLaunchKernelGGL(geometry_kernel<0>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
+    hipLaunchKernelGGL(geometry_kernel, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
     return hipGetLastError();
 }
 
