@@ -1055,6 +1055,10 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
     for (uint32_t base = 0; base < n_total; base += RASTER_CHUNK) {
         if (tid == 0) *lds_count = 0;
         __syncthreads();
+        // opaque copies: what make_tile_rec derives from the tile coordinates is rebuilt per chunk (a few instructions)
+        // instead of being hoisted out of the loops into VGPRs that then spill
+        uint32_t txl = tx, tyl = ty;
+        asm volatile("" : "+s"(txl), "+s"(tyl));
         const uint32_t i = base + ftid;
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
@@ -1065,7 +1069,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
             const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
             hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
-            if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)tx, (int32_t)ty);
+            if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
         }
         bool small = false, boxed = false;
         if (hit) {
@@ -1141,6 +1145,15 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
     const uint32_t nbig_raw = *H.big_count;
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
+    // The counters are re-armed right away (nothing reads them again before this kernel has completed: the next scope
+    // that uses this workspace is ordered behind it), so their values need not stay live across the raster loops.
+    if (tid == 0) {
+        if (count_raw) H.bin_count[tile] = 0;
+        if (tile == 0) {
+            *P.big_count_next = 0;                          // the next scope on this workspace appends to the other counter
+            P.status[1] = nbig_raw;
+        }
+    }
 
     if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
     PixelState st;
@@ -1166,15 +1179,9 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
-            // parameters of this phase are (re)read here, see launder_params
-            const ParamsPtr B = launder_params((ParamsPtr)(uintptr_t)params);
-            if (count && tid == 0) B->bin_count[tile] = 0;  // ready for the next scope that uses this workspace
-            if (tile == 0 && tid == 0) {
-                *B->big_count_next = 0;                     // the next scope on this workspace appends to the other counter
-                B->status[1] = nbig_raw;
-            }
             if (!nbig) break;
-            list = reinterpret_cast<const uint4*>(B->big_recs);
+            // parameters of this phase are (re)read here, see launder_params
+            list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);
             n_list = nbig;
         }
     }
@@ -1197,40 +1204,49 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
     const ParamsPtr R = launder_params((ParamsPtr)(uintptr_t)params);
     const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
     // flat colours of all four owned pixels are requested before the first one is used (four overlapping loads
-    // instead of four dependent round trips in the loop below)
+    // instead of four dependent round trips in the loop below).  A pixel is covered iff its id key moved off the
+    // initial one (no primitive carries NO_PRIM, and the "nothing can pass" state (0, 0) is never replaced).
+    // Addressing is a uniform base plus a 32-bit byte offset per lane (tables and targets stay far below 4 GB).
     uint32_t flat4[4] = {0u, 0u, 0u, 0u};
-    const uint32_t* flat_color = PROGS == 1 && !R->depth_load ? R->flat_color : nullptr;
-    const uint32_t init_zk = R->init_zk, init_idk = R->init_idk;
+    const uint8_t* flat_color = PROGS == 1 && !R->depth_load ? reinterpret_cast<const uint8_t*>(R->flat_color) : nullptr;
+    const uint32_t init_idk = R->init_idk;
     if (flat_color) {
-        const uint32_t idflip = R->idflip;
+        if (R->idflip) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const bool won = !(st.zk[b] == init_zk && st.idk[b] == init_idk);
-            if (won) flat4[b] = flat_color[idflip ? (MAX_PRIM_ID - st.idk[b]) : st.idk[b]];
+            for (int b = 0; b < 4; b++)
+                if (st.idk[b] != init_idk) flat4[b] = *reinterpret_cast<const uint32_t*>(flat_color + ((MAX_PRIM_ID - st.idk[b]) << 2));
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (st.idk[b] != init_idk) flat4[b] = *reinterpret_cast<const uint32_t*>(flat_color + (st.idk[b] << 2));
         }
     }
     // Fast exit for the headline shape of work: every covered pixel of this wave belongs to a flat-coloured
     // triangle whose packed colour the geometry kernel already produced, and only the 8-bit colour target is
     // written.  Same values as the general loop below, a fraction of its instructions.
     if (flat_color && R->color_format != 2 && !R->prim_out && !(R->depth && R->depth_store)) {
-        bool need_shade = false;
-        uint32_t outc[4]; bool won4[4];
-        const uint32_t clear_packed = R->clear_packed;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            won4[b] = !(st.zk[b] == init_zk && st.idk[b] == init_idk);
-            need_shade = need_shade || (won4[b] && flat4[b] == 0u);
-            outc[b] = won4[b] ? flat4[b] : clear_packed;
-        }
+        // a covered pixel without a flat colour has to be shaded: then the whole wave takes the general loop
+        const bool need_shade = (st.idk[0] != init_idk && flat4[0] == 0u) || (st.idk[1] != init_idk && flat4[1] == 0u) ||
+                                (st.idk[2] != init_idk && flat4[2] == 0u) || (st.idk[3] != init_idk && flat4[3] == 0u);
         if (__ballot(need_shade) == 0ull) {
-            const uint32_t width = R->width, height = R->height, color_load = R->color_load;
-            const bool whole = (tx + 1u) * TILE <= width && (ty + 1u) * TILE <= height;     // wave-uniform
-            uint32_t* dst = reinterpret_cast<uint32_t*>(R->color) + (size_t)py0 * width + px0;
+            const uint32_t width = R->width, height = R->height, clear_packed = R->clear_packed;
+            uint8_t* row0 = reinterpret_cast<uint8_t*>(R->color);
+            uint8_t* row1 = row0 + (size_t)BLOCK * width * 4u;                 // the lower pair of blocks: uniform base
+            const uint32_t off = (py0 * width + px0) * 4u;
+            if ((tx + 1u) * TILE <= width && (ty + 1u) * TILE <= height && !R->color_load) {   // wave-uniform: interior tile
+                *reinterpret_cast<uint32_t*>(row0 + off) = st.idk[0] != init_idk ? flat4[0] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row0 + off + 4u * BLOCK) = st.idk[1] != init_idk ? flat4[1] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row1 + off) = st.idk[2] != init_idk ? flat4[2] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row1 + off + 4u * BLOCK) = st.idk[3] != init_idk ? flat4[3] : clear_packed;
+            } else {
+                const uint32_t color_load = R->color_load;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
-                const bool inb = whole || (px < width && py < height);
-                if (inb && (won4[b] || !color_load)) dst[(size_t)(b >> 1) * BLOCK * width + (size_t)(b & 1) * BLOCK] = outc[b];
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+                    const bool won = st.idk[b] != init_idk;
+                    if (px < width && py < height && (won || !color_load))
+                        *reinterpret_cast<uint32_t*>((b >> 1 ? row1 : row0) + off + 4u * BLOCK * (uint32_t)(b & 1)) = won ? flat4[b] : clear_packed;
+                }
             }
             STAMP(4);
             return;
