@@ -32,11 +32,16 @@ namespace mirhi {
 __device__ uint64_t g_stamps[16384 * 8];
 __device__ uint64_t g_stamps_geo[16384 * 4];
 #define GSTAMP(k) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 16384u) g_stamps_geo[blockIdx.x * 4u + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
+#define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
     if (wv < 16384u) g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+// instruction-count attribution: the raster kernel returns after stage g_stage_limit (1 prologue, 2 fill of the first
+// chunk, 3 both lists); the SQ instruction counters of such runs, differenced, give the dynamic cost of each stage
+__device__ uint32_t g_stage_limit;
+#define STAGE_END(k) do { if (g_stage_limit == (k)) return; } while (0)
 #else
 #define STAMP(k) do {} while (0)
 #define GSTAMP(k) do {} while (0)
+#define STAGE_END(k) do {} while (0)
 #endif
 
 struct f3 { float x, y, z; };
@@ -879,22 +884,32 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
     bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
     // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
-    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).
-    int32_t c[3];
+    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
+    // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
+    // block -- no compares, no branches, nothing on the scalar unit.
+    int32_t c[3], a8[3], b8[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
-    uint32_t mask = 0;
-#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
+        a8[i] = A[i] * BLOCK; b8[i] = B[i] * BLOCK;
+    }
+    uint32_t outside = 0;                               // after the loop: bit (15 - (by*4+bx)) set <=> block outside an edge
+#pragma unroll
     for (int by = 0; by < 4; by++) {
+        int32_t v0 = c[0], v1 = c[1], v2 = c[2];
 #pragma unroll
         for (int bx = 0; bx < 4; bx++) {
-            const int32_t lx = bx * BLOCK, hx = lx + BLOCK - 1, ly = by * BLOCK, hy = ly + BLOCK - 1;
-            bool hit = !(hx < bx0 || lx > bx1 || hy < by0 || ly > by1);
-            hit = hit && ((c[0] + A[0] * (bx * BLOCK)) | (c[1] + A[1] * (bx * BLOCK)) | (c[2] + A[2] * (bx * BLOCK))) >= 0;
-            mask |= hit ? (1u << (by * 4 + bx)) : 0u;
+            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)(v0 | v1 | v2), 31);   // (outside << 1) | sign
+            v0 += a8[0]; v1 += a8[1]; v2 += a8[2];
         }
-        c[0] += B[0] * BLOCK; c[1] += B[1] * BLOCK; c[2] += B[2] * BLOCK;
+        c[0] += b8[0]; c[1] += b8[1]; c[2] += b8[2];
     }
+    // pixel box -> block box -> mask of the blocks inside it (4 column bits replicated per row, row bits spread to nibbles)
+    const uint32_t cols = ((2u << ((uint32_t)bx1 >> 3)) - 1u) & ~((1u << ((uint32_t)bx0 >> 3)) - 1u);          // bits bx0b..bx1b
+    const uint32_t rows = ((2u << ((uint32_t)by1 >> 3)) - 1u) & ~((1u << ((uint32_t)by0 >> 3)) - 1u);
+    const uint32_t rowsel = ((rows & 1u) * 0xFu) | ((rows & 2u) * 0x78u) | ((rows & 4u) * 0x3C0u) | ((rows & 8u) * 0x1E00u);
+    const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
+    const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
     const float inv256 = 1.0f / 256.0f;
     const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
     const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
@@ -1099,7 +1114,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         }
         __syncthreads();
         const uint32_t n = *lds_count;
-        if (base == 0) STAMP(5);
+        if (base == 0) { STAMP(5); STAGE_END(2u); }
         if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
     }
 }
@@ -1170,6 +1185,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
     }
 
     STAMP(1);
+    STAGE_END(1u);
     // the tile's bin, then the list every tile tests (large / clipped / spilled triangles): one copy of the code
     const uint4* list = reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u;
     uint32_t n_list = count;
@@ -1187,6 +1203,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
     }
 
     STAMP(3);
+    STAGE_END(3u);
     if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
     // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
@@ -1345,6 +1362,9 @@ extern "C" int mirhi_debug_read_stamps(uint64_t* dst, uint32_t count) {
 }
 extern "C" int mirhi_debug_read_geo_stamps(uint64_t* dst, uint32_t count) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_geo), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mirhi_debug_set_stage_limit(uint32_t v) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stage_limit), &v, sizeof v, 0, hipMemcpyHostToDevice);
 }
 extern "C" int mirhi_debug_clear_stamps() {
     void* p = nullptr;
