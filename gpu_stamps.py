@@ -4,11 +4,12 @@ import __graft_entry__ as ge
 m = ge.load_package()
 L = C.CDLL(m.LIB_PATH)
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
-make = {"tri1": lambda: m.scenes.random_triangles(1), "c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid}[wl]
+make = {"tri1": lambda: m.scenes.random_triangles(1), "c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid, "c5": m.scenes.box_hall}[wl]
 scene = make()
 dev = m.Device(0)
 res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
-for _ in range(20): res.render()
+for _ in range(3):
+    res.render(); dev.wait_idle()
 dev.wait_idle()
 def grab(kernel_waves):
     buf = np.zeros(16384 * 8, dtype=np.uint64)

@@ -520,23 +520,30 @@ __device__ __forceinline__ f3 blinn_phong(f3 L, f3 V, f3 N, f3 lightColor, f3 al
     return add3(diffuse, scale3(lightColor, sp));
 }
 
-__device__ __forceinline__ f4 texel(const uint8_t* tex, int32_t w, int32_t h, int32_t x, int32_t y) {
-    x %= w; if (x < 0) x += w;
-    y %= h; if (y < 0) y += h;
-    const uint32_t p = reinterpret_cast<const uint32_t*>(tex)[(uint32_t)y * (uint32_t)w + (uint32_t)x];
+__device__ __forceinline__ f4 unpack_rgba8(uint32_t p) {
     const float s = 1.0f / 255.0f;
     return {(float)(p & 0xFF) * s, (float)((p >> 8) & 0xFF) * s, (float)((p >> 16) & 0xFF) * s, (float)(p >> 24) * s};
+}
+// repeat addressing of one coordinate: c mod n into [0, n); a mask when n is a power of two (the usual case),
+// one division otherwise.  The +1 neighbour wraps by comparison, so a bilinear tap costs two of these, not eight.
+__device__ __forceinline__ int32_t wrap_coord(int32_t c, int32_t n) {
+    if ((n & (n - 1)) == 0) return c & (n - 1);          // n is wave-uniform: a scalar branch
+    c %= n;
+    return c < 0 ? c + n : c;
 }
 // bilinear, repeat, no mips (see oracle sample_bilinear)
 __device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, uint32_t h, float u, float v) {
     if (!tex || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
-    if (w == 1 && h == 1) return texel(tex, 1, 1, 0, 0);
+    const uint32_t* texels = reinterpret_cast<const uint32_t*>(tex);
+    if (w == 1 && h == 1) return unpack_rgba8(texels[0]);
     const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float ax = fx - x0f, ay = fy - y0f;
-    const int32_t x0 = (int32_t)x0f, y0 = (int32_t)y0f;
-    const f4 c00 = texel(tex, w, h, x0, y0), c10 = texel(tex, w, h, x0 + 1, y0);
-    const f4 c01 = texel(tex, w, h, x0, y0 + 1), c11 = texel(tex, w, h, x0 + 1, y0 + 1);
+    const int32_t x0 = wrap_coord((int32_t)x0f, (int32_t)w), y0 = wrap_coord((int32_t)y0f, (int32_t)h);
+    const int32_t x1 = x0 + 1 == (int32_t)w ? 0 : x0 + 1, y1 = y0 + 1 == (int32_t)h ? 0 : y0 + 1;
+    const uint32_t r0 = (uint32_t)y0 * w, r1 = (uint32_t)y1 * w;
+    const f4 c00 = unpack_rgba8(texels[r0 + (uint32_t)x0]), c10 = unpack_rgba8(texels[r0 + (uint32_t)x1]);
+    const f4 c01 = unpack_rgba8(texels[r1 + (uint32_t)x0]), c11 = unpack_rgba8(texels[r1 + (uint32_t)x1]);
     f4 r;
 #define MIRHI_LERP2(f) { const float top = c00.f + (c10.f - c00.f) * ax; const float bot = c01.f + (c11.f - c01.f) * ax; r.f = top + (bot - top) * ay; }
     MIRHI_LERP2(x) MIRHI_LERP2(y) MIRHI_LERP2(z) MIRHI_LERP2(w)
@@ -1160,14 +1167,13 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
     const uint32_t nbig_raw = *H.big_count;
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
-    // The counters are re-armed right away (nothing reads them again before this kernel has completed: the next scope
-    // that uses this workspace is ordered behind it), so their values need not stay live across the raster loops.
-    if (tid == 0) {
-        if (count_raw) H.bin_count[tile] = 0;
-        if (tile == 0) {
-            *P.big_count_next = 0;                          // the next scope on this workspace appends to the other counter
-            P.status[1] = nbig_raw;
-        }
+    // The big-list counters are re-armed right away (no workgroup reads the other parity's counter, and the next scope
+    // that uses this workspace is ordered behind this kernel), so nbig_raw need not stay live across the raster loops.
+    // The tile's own bin counter is re-armed after the bin pass: every wave of this workgroup reads it above, and the
+    // barriers of that pass order those reads before the store.
+    if (tid == 0 && tile == 0) {
+        *P.big_count_next = 0;                              // the next scope on this workspace appends to the other counter
+        P.status[1] = nbig_raw;
     }
 
     if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
@@ -1195,6 +1201,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
+            if (count && tid == 0) H.bin_count[tile] = 0;   // ready for the next scope that uses this workspace
             if (!nbig) break;
             // parameters of this phase are (re)read here, see launder_params
             list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);

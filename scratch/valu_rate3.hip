@@ -39,6 +39,12 @@ __device__ __forceinline__ void visit(const uint4* lds_rec, uint32_t j, int32_t 
             const uint64_t key = ((uint64_t)zke << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
             const bool upd = key < cur;
             st.zk[b] = upd ? zke : st.zk[b]; st.idk[b] = upd ? idk : st.idk[b];
+        } else if (VAR == 4) {   // keys as positive doubles (bigger = nearer), outside lanes negative: one v_max_f64 replaces compare + selects
+            const uint32_t hi = (0x7FEFFFFFu - zk) | ((uint32_t)(S0 | S1 | S2) & 0x80000000u);
+            const double nk = __longlong_as_double((long long)(((uint64_t)hi << 32) | (uint32_t)~idk));
+            const double ck = __longlong_as_double((long long)(((uint64_t)st.zk[b] << 32) | st.idk[b]));
+            const unsigned long long r = (unsigned long long)__double_as_longlong(__builtin_fmax(ck, nk));
+            st.zk[b] = (uint32_t)(r >> 32); st.idk[b] = (uint32_t)r;
         } else if (VAR == 3) {   // sign trick: OR the edge sign bit into the depth key (covered -> unchanged, outside -> >= 0x80000000)
             const uint32_t zke = zk | ((uint32_t)(S0 | S1 | S2) & 0x80000000u);
             const uint64_t key = ((uint64_t)zke << 32) | idk, cur = ((uint64_t)st.zk[b] << 32) | st.idk[b];
@@ -96,6 +102,7 @@ int main() {
     const uint32_t c1 = run<1>("branchy update", d, recs);
     run<2>("outside -> max key (select on inside)", d, recs);
     run<3>("edge sign bit ORed into depth key", d, recs);
+    run<4>("double-typed key + v_max_f64", d, recs);
     printf("variants 0/1 agree: %d (2/3 store a different non-covered key by construction)\n", c0 == c1);
     return 0;
 }
