@@ -1156,7 +1156,7 @@ extern "C" mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t e
     NULL_CHECK(dev, "device");
     std::lock_guard<std::mutex> lock(dev->mu);
     if (enable && dev->event_overhead_ms == 0.0) {
-        // An event pair costs ~4-5 us of stream time on this part even around nothing (scratch/evt.hip).
+        // An event pair costs ~4-5 us of stream time on this part even around nothing (tools/microbench/evt.hip).
         // Calibrate it once and subtract it per launch so reported kernel durations agree with rocprofv3.
         HIP_TRY(hipSetDevice(dev->ordinal));
         const int n = 64;

@@ -1,5 +1,7 @@
 """Renders N frames of one workload (for rocprofv3). usage: prof_run.py <c2|c3|c4|c5> [frames] [bgra8|rgba32f]"""
 import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 m = ge.load_package()
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"

@@ -1,5 +1,7 @@
 import os, sys, ctypes as C, numpy as np
 os.environ["MIRHI_LIB_NAME"] = "libmirhi_stamps.so"
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 m = ge.load_package()
 L = C.CDLL(m.LIB_PATH)
