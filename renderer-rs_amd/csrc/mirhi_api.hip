@@ -125,7 +125,7 @@ struct RecordedPass {
     std::vector<uint64_t> draw_vb_bytes;   // bytes of the bound vertex buffer range per draw (vertex pre-pass extent)
     uint32_t total_tris = 0;
     bool key_set = false;
-    uint32_t depth_test = 0, depth_compare = 0;
+    uint32_t depth_test = 0, depth_compare = 0, depth_write = 0;
     int32_t area[4] = {0, 0, 0, 0};
 };
 
@@ -499,10 +499,10 @@ extern "C" mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pip
     if (d->rasterization_samples != 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported sample count %u", d->rasterization_samples);
     if (d->blend_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: blending (opaque overwrite only)");
     if (d->depth_clamp_enable || d->depth_bias_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth clamp / depth bias");
-    if (d->depth_test_enable && !d->depth_write_enable && d->depth_compare_op != MIRHI_COMPARE_ALWAYS && d->depth_compare_op != MIRHI_COMPARE_NEVER)
-        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth test without depth write");
-    if (d->depth_test_enable && (d->depth_compare_op == MIRHI_COMPARE_EQUAL || d->depth_compare_op == MIRHI_COMPARE_NOT_EQUAL))
-        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported depth compare op %d (Equal / NotEqual)", d->depth_compare_op);
+    // NotEqual with depth write makes the stored depth depend on the order of ALL fragments of a pixel, passing or not: it
+    // cannot be resolved by a per-pixel minimum (DESIGN.md "Depth key") and is refused rather than drawn wrong
+    if (d->depth_test_enable && d->depth_write_enable && d->depth_compare_op == MIRHI_COMPARE_NOT_EQUAL)
+        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth compare NotEqual together with depth write");
     const uint32_t want_stride = vs_model ? 48u : 24u;      // vertex.rs:35-41 / :130-136
     if (d->vertex_stride < want_stride || (d->vertex_stride & 3u))
         return fail(MIRHI_ERR_PIPELINE, "Pipeline error: vertex stride %u too small for program %d (needs >= %u, multiple of 4)", d->vertex_stride, d->vertex_program, want_stride);
@@ -701,16 +701,18 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     if (pd.color_attachment_formats[0] != (int32_t)ci->format)
         return fail(MIRHI_ERR_PIPELINE, "Pipeline error: pipeline colour format %d does not match the attachment format %d", pd.color_attachment_formats[0], (int)ci->format);
     // depth state must be uniform within a rendering scope (DESIGN.md "Depth key")
-    const uint32_t dtest = pd.depth_test_enable && pd.depth_compare_op != MIRHI_COMPARE_ALWAYS ? 1u : 0u;
+    const uint32_t dtest = pd.depth_test_enable ? 1u : 0u;
     const uint32_t dcmp = dtest ? (uint32_t)pd.depth_compare_op : (uint32_t)MIRHI_COMPARE_ALWAYS;
+    const uint32_t dwrite = dtest && pd.depth_write_enable ? 1u : 0u;       // Vulkan: no depth write without the depth test
     const bool never = pd.depth_test_enable && pd.depth_compare_op == MIRHI_COMPARE_NEVER;
     if (!never) {
-        if (!pass.key_set) { pass.key_set = true; pass.depth_test = dtest; pass.depth_compare = dcmp; }
-        else if (pass.depth_test != dtest || pass.depth_compare != dcmp)
+        if (!pass.key_set) { pass.key_set = true; pass.depth_test = dtest; pass.depth_compare = dcmp; pass.depth_write = dwrite; }
+        else if (pass.depth_test != dtest || pass.depth_compare != dcmp || pass.depth_write != dwrite)
             return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: pipelines with different depth test state inside one rendering scope");
     }
     const uint32_t tri_count = count / 3u;
-    if (instance_count == 0 || tri_count == 0 || never) return MIRHI_OK;
+    if (instance_count == 0 || tri_count == 0) return MIRHI_OK;
+    if (never) { pass.total_tris += tri_count; return MIRHI_OK; }     // draws nothing, but its primitives keep their ids
 
     DrawDesc d;
     memset(&d, 0, sizeof d);
@@ -802,9 +804,26 @@ static mirhi_result grow(T** ptr, size_t* have, size_t want_bytes) {
 static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
     const uint32_t cbits = [&] { float f = pass.info.clear_depth; f = f > 0.0f ? (f < 1.0f ? f : 1.0f) : 0.0f; uint32_t u; memcpy(&u, &f, 4); return u; }();
     P.clear_depth_bits = cbits;
+    P.pred = 0;
     const uint32_t op = pass.key_set ? pass.depth_compare : (uint32_t)MIRHI_COMPARE_ALWAYS;
     const bool test = pass.key_set && pass.depth_test;
-    if (!test || op == MIRHI_COMPARE_ALWAYS) { P.zflip = 0; P.zmask = 0; P.idflip = 1; P.strict = 0; P.init_zk = 0; P.init_idk = NO_PRIM; return; }
+    const bool write = test && pass.depth_write;
+    if (!test || (op == MIRHI_COMPARE_ALWAYS && !write)) {      // every fragment passes, nothing is written: later primitive wins
+        P.zflip = 0; P.zmask = 0; P.idflip = 1; P.strict = 0; P.init_zk = 0; P.init_idk = NO_PRIM; return;
+    }
+    const bool ordered = write && (op == MIRHI_COMPARE_LESS || op == MIRHI_COMPARE_LESS_OR_EQUAL || op == MIRHI_COMPARE_GREATER ||
+                                   op == MIRHI_COMPARE_GREATER_OR_EQUAL);
+    if (!ordered) {
+        // Predicate mode.  Without depth write (or with Equal, which can only rewrite the same value) the stored depth
+        // never changes inside the scope: every fragment is tested against the depth the scope started with and the latest
+        // passing primitive owns the pixel.  Always with write: everything passes, the latest primitive's depth is stored.
+        static const uint32_t bits[8] = {0u, 1u, 2u, 3u, 4u, 5u, 6u, 7u};     // Never, Less, Equal, LessOrEqual, Greater, NotEqual, GreaterOrEqual, Always
+        P.pred = bits[op & 7u] | (op == MIRHI_COMPARE_ALWAYS ? 8u : 0u);
+        if (P.pred == 0) P.pred = 16u;                                           // (Never is dropped at record time; keep the mode bit set)
+        P.zflip = 0; P.zmask = 0xFFFFFFFFu; P.idflip = 1; P.strict = 0;
+        P.init_zk = cbits; P.init_idk = NO_PRIM;
+        return;
+    }
     const bool greater = (op == MIRHI_COMPARE_GREATER || op == MIRHI_COMPARE_GREATER_OR_EQUAL);
     P.strict = (op == MIRHI_COMPARE_LESS || op == MIRHI_COMPARE_GREATER) ? 1u : 0u;
     P.zflip = greater ? 0xFFFFFFFFu : 0u;
@@ -958,6 +977,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
             const bool dense = tiles && pass.total_tris / tiles >= 16;
             P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 128u : 0u);
+            if (P.pred) P.tp_max_area = 0;    // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();

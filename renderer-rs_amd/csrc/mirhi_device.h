@@ -94,6 +94,8 @@ struct PassParams {
     // depth key (DESIGN.md "Depth key"): zk = (bits(z) ^ zflip) & zmask ; idk = idflip ? MAX-id : id
     uint32_t zflip, zmask, idflip;
     uint32_t strict;                  // compare op is LESS / GREATER (ties with the stored depth fail)
+    uint32_t pred;                    // != 0: predicate mode -- bit 0/1/2: a fragment passes when its depth is </==/> the scope's
+                                      // initial depth; bit 3: the winner's depth replaces it (ALWAYS with depth write)
     uint32_t init_zk, init_idk;       // state of an uncovered pixel when depth is cleared
     uint32_t clear_depth_bits;
     float    clear_color[4];

@@ -929,7 +929,8 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
 }
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
-// KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied).
+// KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied);
+//         2: predicate against the scope's initial depth (see DESIGN.md "Depth key").
 // d = (a << 3) + b in one instruction (8 = BLOCK: the step of an edge function from one 8x8 block to the next)
 __device__ __forceinline__ int32_t step8(int32_t a, int32_t b) {
     int32_t d;
@@ -965,7 +966,7 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
         // clamp to [0,1]: v_med3_f32 returns min3 = 0 when z is NaN; the mask turns a -0 result into +0
         uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
         bool upd;
-        if (!KEYED && !BOXED) {
+        if (KEYED == 0 && !BOXED) {
             // plain key: depth bits are <= 0x3F800000, so a lane outside the triangle can carry its miss in the key's
             // top bit (such a key never beats a stored one) -- no separate compare, no mask AND
             zk |= (uint32_t)sgn & 0x80000000u;             // (an updating lane has the bit clear: zk is stored unchanged)
@@ -977,8 +978,18 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
                 inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
                          iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
             }
-            if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
-            upd = inside && (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+            if (KEYED == 2) {
+                // predicate mode (depth test without write, EQUAL, ALWAYS with write): the fragment is tested against the
+                // depth the scope started with (kept in st.zk), the latest passing primitive wins (idk = MAX - id)
+                const uint32_t pred = P.pred;
+                const bool lt = zk < st.zk[b], eq = zk == st.zk[b];
+                const bool pass = (lt && (pred & 1u)) || (eq && (pred & 2u)) || (!lt && !eq && (pred & 4u));
+                upd = inside && pass && idk < st.idk[b];
+                if (!(pred & 8u)) zk = st.zk[b];           // only ALWAYS-with-write replaces the depth (by the winner's)
+            } else {
+                if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+                upd = inside && (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+            }
         }
         st.zk[b] = upd ? zk : st.zk[b];
         st.idk[b] = upd ? idk : st.idk[b];
@@ -1038,7 +1049,7 @@ __device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, u
                 const float dx = (float)ix + dxt;
                 const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
                 uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
-                if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+                if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
                 atomicMin(&lds_key[iy * TILE + ix], ((unsigned long long)zk << 32) | idk);
             }
             s0 += A0; s1 += A1; s2 += A2;
@@ -1358,7 +1369,8 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     const RasterHead H = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap};
-    if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream); }
+    if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream);          // (the host keeps tp_max_area = 0 for predicate scopes)
+    else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream); }
     else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream); }
     return hipGetLastError();
 }

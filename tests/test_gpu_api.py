@@ -63,7 +63,10 @@ def test_pipeline_build_validation_order_and_text(mirhi, device):
     assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).blend_enable(True))
     assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).topology(mirhi.PrimitiveTopology.TriangleStrip))
     assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).polygon_mode(mirhi.PolygonMode.Line))
-    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.Equal))
+    assert "unsupported" in err(_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.NotEqual))
+    for ok in (_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.Equal),
+               _tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_write_enable(False).depth_compare_op(mirhi.CompareOp.NotEqual)):
+        ok.build(device).destroy()          # predicate depth states are supported
     mixed = (B().vertex_shader(mirhi.Program.MODEL).fragment_shader(mirhi.Program.TRIANGLE).vertex_binding(48)
              .vertex_attributes((0, 12, 24, 32)).color_attachment_format(mirhi.Format.R32G32B32A32_SFLOAT)
              .depth_attachment_format(mirhi.Format.D32_SFLOAT))
@@ -316,3 +319,74 @@ def test_pbr_textured_alpha_cutoff_is_reported(mirhi, oracle, device, scenes):
     f.wait()
     f.destroy()
     res.destroy()
+
+
+@pytest.mark.parametrize("op,write", [("Less", False), ("LessOrEqual", False), ("Greater", False), ("GreaterOrEqual", False),
+                                      ("Equal", False), ("NotEqual", False), ("Equal", True), ("Always", True), ("Never", True)])
+def test_predicate_depth_states_second_scope(mirhi, oracle, device, scenes, op, write):
+    """Depth test without depth write, Equal (the depth-pre-pass pattern), Always with write and Never
+    (pipeline.rs:375-409,677-679): scope 1 lays down depth with Less + write, scope 2 loads it and draws with the state
+    under test.  The oracle applies the same fragments one by one in submission order."""
+    W, H = 224, 144
+    a = scenes.random_triangles(150, W, H, seed=41, rmin=6, rmax=60).draws[0]
+    extra = scenes.random_triangles(150, W, H, seed=42, rmin=6, rmax=60).draws[0]
+    # scope 2 draws A's triangles again (so Equal has something to hit) followed by unrelated ones, in new colours
+    vb2 = np.concatenate([a.vertices.reshape(-1, 6), extra.vertices.reshape(-1, 6)], axis=0).copy()
+    vb2[:, 3:6] = 1.0 - vb2[:, 3:6]
+    cmp_ = getattr(scenes, {"Less": "CMP_LESS", "LessOrEqual": "CMP_LESS_OR_EQUAL", "Greater": "CMP_GREATER",
+                            "GreaterOrEqual": "CMP_GREATER_OR_EQUAL", "Equal": "CMP_EQUAL", "NotEqual": "CMP_NOT_EQUAL",
+                            "Always": "CMP_ALWAYS", "Never": "CMP_NEVER"}[op])
+    b = scenes.DrawSpec(vertices=vb2, stride=24, count=vb2.shape[0], cull_mode=scenes.CULL_NONE, depth_test=True,
+                        depth_write=write, depth_compare=cmp_)
+    both = scenes.Scene("pred", W, H, [a, b], clear_color=(0.2, 0.1, 0.3, 1.0))
+    ref = oracle.render(both, want_bgra8=False)
+    color = mirhi.Image(device, W, H, mirhi.Format.R32G32B32A32_SFLOAT)
+    depth = mirhi.Image(device, W, H, mirhi.Format.D32_SFLOAT)
+    base = lambda: _tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).cull_mode(mirhi.CullMode.NONE)
+    pipe_a = base().build(device)
+    pipe_b = base().depth_write_enable(write).depth_compare_op(getattr(mirhi.CompareOp, op)).build(device)
+    vba = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, a.vertices)
+    vbb = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, vb2)
+    cmd = mirhi.CommandBuffer(device)
+    cmd.begin()
+    for i, (vb, d, pipe) in enumerate(((vba, a, pipe_a), (vbb, b, pipe_b))):
+        cmd.begin_rendering(color, clear_color=both.clear_color, color_load_op=mirhi.LoadOp.CLEAR if i == 0 else mirhi.LoadOp.LOAD,
+                            depth=depth, depth_load_op=mirhi.LoadOp.CLEAR if i == 0 else mirhi.LoadOp.LOAD,
+                            depth_store_op=mirhi.StoreOp.STORE)
+        cmd.set_viewport(0, 0, W, H)
+        cmd.set_scissor(0, 0, W, H)
+        cmd.bind_pipeline(pipe)
+        cmd.bind_vertex_buffers(0, [vb], [0])
+        cmd.draw(d.count)
+        cmd.end_rendering()
+    cmd.end()
+    device.submit([cmd])
+    device.wait_idle()
+    got_c, got_d = color.read(), depth.read()
+    assert np.array_equal(got_d.view(np.uint32), ref["depth"].view(np.uint32)), f"{op} write={write}: depth differs"
+    assert np.abs(got_c[..., :3] - ref["rgba"][..., :3]).max() < 1e-4, f"{op} write={write}: colour differs"
+    for o in (cmd, vba, vbb, pipe_a, pipe_b, color, depth):
+        o.destroy()
+
+
+def test_predicate_depth_state_against_cleared_depth(mirhi, oracle, device, scenes):
+    """Depth test without write in a single scope: every fragment is tested against the clear value, the last passing one
+    stays (SceneResources path, 8-bit target + primitive ids)."""
+    sc = scenes.random_triangles(400, 320, 200, seed=43, rmin=4, rmax=50)
+    d = sc.draws[0]
+    d.depth_write = False
+    d.depth_compare = scenes.CMP_GREATER
+    sc.clear_depth = 0.5
+    res = mirhi.SceneResources(device, sc, mirhi.Format.B8G8R8A8_SRGB, want_prim=True)
+    res.render()
+    out = res.read()
+    ref = oracle.render(sc, want_bgra8=True)
+    assert np.array_equal(out["prim"], ref["prim"])
+    assert np.abs(out["color"].astype(np.int32) - ref["bgra8"].astype(np.int32)).max() <= 1
+    res.destroy()
+
+
+def test_not_equal_with_write_is_refused(mirhi, device):
+    with pytest.raises(mirhi.RhiError) as e:
+        (_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.NotEqual).build(device))
+    assert e.value.code == 9 and "NotEqual" in e.value.message

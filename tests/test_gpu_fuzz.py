@@ -172,3 +172,23 @@ def test_fuzz_pbr_against_oracle(mirhi, oracle, device, scenes, seed):
     assert np.array_equal(np.isnan(a), nan)
     err = np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b)))
     assert err.max() < 1e-4, f"{scene.name}: max |dRGBA| {err.max()}"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_predicate_depth_states(mirhi, oracle, device, scenes, seed):
+    """The random scenes of test_fuzz_against_oracle with the scope's depth state replaced by a predicate one: depth test
+    without write for all eight compare ops, Equal and Always with write (DESIGN.md "Depth key")."""
+    scene = _random_scene(scenes, 5000 + seed)
+    rng = np.random.default_rng(7000 + seed)
+    states = [(op, False) for op in range(8)] + [(scenes.CMP_EQUAL, True), (scenes.CMP_ALWAYS, True)]
+    op, write = states[int(rng.integers(0, len(states)))]
+    for d in scene.draws:
+        d.depth_test, d.depth_write, d.depth_compare = True, write, op
+    scene.clear_depth = float(rng.choice([0.0, 0.25, 0.5, 1.0]))
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"]), f"{scene.name} op {op} write {write}: winning primitive differs"
+    assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32)), f"{scene.name} op {op} write {write}: depth differs"
