@@ -126,6 +126,10 @@ struct RecordedPass {
     uint32_t total_tris = 0;
     bool key_set = false;
     uint32_t depth_test = 0, depth_compare = 0, depth_write = 0;
+    // a scope whose pipelines change the depth state is continued in a new segment: colour is kept (LOAD), depth is
+    // carried through the depth attachment or, without one, a transient buffer of the workspace
+    uint32_t first_tri = 0;                // primitive ids continue across the segments of a scope
+    bool carry_in = false, carry_out = false;
     int32_t area[4] = {0, 0, 0, 0};
 };
 
@@ -135,6 +139,7 @@ struct Workspace {
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
+    float* carry_depth = nullptr; size_t carry_depth_bytes = 0;   // depth hand-over between the segments of a scope without a depth attachment
     PassParams* params = nullptr; size_t params_bytes = 0;   // two copies per scope (big-list counter parity 0 / 1), read by the kernels
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
@@ -545,6 +550,7 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.big_recs) (void)hipFree(w.big_recs);
     if (w.vs_jobs) (void)hipFree(w.vs_jobs);
     if (w.params) (void)hipFree(w.params);
+    if (w.carry_depth) (void)hipFree(w.carry_depth);
     if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.flat_color) (void)hipFree(w.flat_color);
     if (w.status_host) (void)hipHostFree(w.status_host);
@@ -695,9 +701,8 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     if (indexed && !cmd->ib) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: no index buffer bound");
     if (!cmd->has_viewport || !cmd->has_scissor) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: viewport and scissor are dynamic state and must be set before drawing (pipeline.rs:697)");
     if (instance_count > 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: instance_count %u (1 supported)", instance_count);
-    RecordedPass& pass = cmd->passes.back();
     const mirhi_pipeline_desc& pd = cmd->pipeline->desc;
-    const mirhi_image* ci = pass.info.color_image;
+    const mirhi_image* ci = cmd->passes.back().info.color_image;
     if (pd.color_attachment_formats[0] != (int32_t)ci->format)
         return fail(MIRHI_ERR_PIPELINE, "Pipeline error: pipeline colour format %d does not match the attachment format %d", pd.color_attachment_formats[0], (int)ci->format);
     // depth state must be uniform within a rendering scope (DESIGN.md "Depth key")
@@ -705,14 +710,29 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     const uint32_t dcmp = dtest ? (uint32_t)pd.depth_compare_op : (uint32_t)MIRHI_COMPARE_ALWAYS;
     const uint32_t dwrite = dtest && pd.depth_write_enable ? 1u : 0u;       // Vulkan: no depth write without the depth test
     const bool never = pd.depth_test_enable && pd.depth_compare_op == MIRHI_COMPARE_NEVER;
-    if (!never) {
-        if (!pass.key_set) { pass.key_set = true; pass.depth_test = dtest; pass.depth_compare = dcmp; pass.depth_write = dwrite; }
-        else if (pass.depth_test != dtest || pass.depth_compare != dcmp || pass.depth_write != dwrite)
-            return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: pipelines with different depth test state inside one rendering scope");
-    }
     const uint32_t tri_count = count / 3u;
     if (instance_count == 0 || tri_count == 0) return MIRHI_OK;
-    if (never) { pass.total_tris += tri_count; return MIRHI_OK; }     // draws nothing, but its primitives keep their ids
+    if (never) { cmd->passes.back().total_tris += tri_count; return MIRHI_OK; }     // draws nothing, but its primitives keep their ids
+    if (!cmd->passes.back().key_set) {
+        RecordedPass& p0 = cmd->passes.back();
+        p0.key_set = true; p0.depth_test = dtest; p0.depth_compare = dcmp; p0.depth_write = dwrite;
+    } else if (cmd->passes.back().depth_test != dtest || cmd->passes.back().depth_compare != dcmp || cmd->passes.back().depth_write != dwrite) {
+        // One raster launch resolves one depth state (DESIGN.md "Depth key"): the scope continues in a new segment that
+        // loads what the previous one stored -- fragments keep their submission order across the cut.
+        RecordedPass next;
+        {
+            RecordedPass& prev = cmd->passes.back();
+            prev.carry_out = true;
+            next.info = prev.info;
+            memcpy(next.area, prev.area, sizeof next.area);
+            next.info.color_load_op = MIRHI_LOAD_OP_LOAD;
+            next.carry_in = true;
+            next.first_tri = next.total_tris = prev.total_tris;
+        }
+        next.key_set = true; next.depth_test = dtest; next.depth_compare = dcmp; next.depth_write = dwrite;
+        cmd->passes.push_back(std::move(next));
+    }
+    RecordedPass& pass = cmd->passes.back();
 
     DrawDesc d;
     memset(&d, 0, sizeof d);
@@ -922,6 +942,15 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     }
     if ((r = grow(&w.vs_out, &w.vs_out_bytes, vs_bytes_max ? vs_bytes_max : 256)) != MIRHI_OK) return r;
     if ((r = grow(&w.vs_jobs, &w.vs_jobs_bytes, (jobs_total ? jobs_total : 1) * sizeof(VsJob))) != MIRHI_OK) return r;
+    {
+        size_t carry = 0;
+        for (auto& pass : cmd->passes)
+            if ((pass.carry_in || pass.carry_out) && !pass.info.depth_image) {
+                const size_t need = (size_t)pass.info.color_image->width * pass.info.color_image->height * 4;
+                if (need > carry) carry = need;
+            }
+        if (carry && (r = grow(&w.carry_depth, &w.carry_depth_bytes, carry)) != MIRHI_OK) return r;
+    }
     if ((r = grow(&w.params, &w.params_bytes, (cmd->passes.size() ? cmd->passes.size() : 1) * 2 * sizeof(PassParams))) != MIRHI_OK) return r;
     std::vector<VsJob> all_jobs;
     all_jobs.reserve(jobs_total);
@@ -962,7 +991,11 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             P.depth = (float*)pass.info.depth_image->ptr;
             P.depth_load = pass.info.depth_load_op == MIRHI_LOAD_OP_LOAD ? 1u : 0u;
             P.depth_store = pass.info.depth_store_op == MIRHI_STORE_OP_STORE ? 1u : 0u;
+        } else if (pass.carry_in || pass.carry_out) {
+            P.depth = w.carry_depth;               // no depth attachment: the segments of the scope hand depth over here
         }
+        if (pass.carry_in) P.depth_load = 1u;
+        if (pass.carry_out) P.depth_store = 1u;
         P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
@@ -975,7 +1008,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         {   // triangle-parallel resolve of small records pays when tiles hold many triangles (meshes); sparse scopes keep
             // the leaner pixel-parallel-only kernel.  MIRHI_TP_MAX_AREA overrides (0 = off) for A/B measurements.
             const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-            const bool dense = tiles && pass.total_tris / tiles >= 16;
+            const bool dense = tiles && (pass.total_tris - pass.first_tri) / tiles >= 16;
             P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 128u : 0u);
             if (P.pred) P.tp_max_area = 0;    // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
         }
@@ -998,7 +1031,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         uint32_t progs = 0;
         for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : (dd.program == MIRHI_PROGRAM_MODEL_PBR ? 4u : 2u);
         cmd->plan_programs.push_back(progs ? progs : 1u);
-        cmd->plan_tris += pass.total_tris;
+        cmd->plan_tris += pass.total_tris - pass.first_tri;
     }
     if (!all.empty()) {
         HIP_TRY(hipMemcpyAsync(w.draws, all.data(), all.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, stream));

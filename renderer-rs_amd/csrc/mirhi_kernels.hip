@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? 8 : (PROGS == 2 ? 5 :
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
             else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));
         }
-        if (P.prim_out) P.prim_out[pix] = prim;
+        if (P.prim_out && !(none && P.color_load)) P.prim_out[pix] = prim;     // LOAD keeps what an earlier scope / segment wrote
         if (P.depth && P.depth_store) {
             const uint32_t zb = (none || !P.zmask) ? zorig : (zkb ^ P.zflip);
             P.depth[pix] = __uint_as_float(zb);

@@ -390,3 +390,32 @@ def test_not_equal_with_write_is_refused(mirhi, device):
     with pytest.raises(mirhi.RhiError) as e:
         (_tri_builder(mirhi).depth_attachment_format(mirhi.Format.D32_SFLOAT).depth_compare_op(mirhi.CompareOp.NotEqual).build(device))
     assert e.value.code == 9 and "NotEqual" in e.value.message
+
+
+@pytest.mark.parametrize("want_depth", [False, True])
+def test_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, want_depth):
+    """Pipelines with different depth state inside ONE rendering scope (opaque Less + write, then a far 'sky' quad with
+    LessOrEqual and no write, then an overlay without depth test, then Less + write again): the scope is cut into segments
+    that hand colour and depth over, with or without a depth attachment; the result equals the oracle's fragment-by-fragment
+    order."""
+    W, H = 256, 176
+    opaque = scenes.random_triangles(200, W, H, seed=51, rmin=6, rmax=70).draws[0]
+    sky = np.array([[-1, -1, 1.0, 0.1, 0.2, 0.6], [1, -1, 1.0, 0.1, 0.2, 0.6], [1, 1, 1.0, 0.3, 0.5, 0.9],
+                    [-1, -1, 1.0, 0.1, 0.2, 0.6], [1, 1, 1.0, 0.3, 0.5, 0.9], [-1, 1, 1.0, 0.3, 0.5, 0.9]], dtype=np.float32)
+    sky_d = scenes.DrawSpec(vertices=sky, stride=24, count=6, cull_mode=scenes.CULL_NONE, depth_test=True, depth_write=False,
+                            depth_compare=scenes.CMP_LESS_OR_EQUAL)
+    overlay = scenes.random_triangles(12, W, H, seed=52, rmin=8, rmax=30).draws[0]
+    overlay.depth_test = False
+    overlay.depth_write = False
+    more = scenes.random_triangles(150, W, H, seed=53, rmin=6, rmax=70).draws[0]
+    sc = scenes.Scene("mixed", W, H, [opaque, sky_d, overlay, more], clear_color=(0.0, 0.0, 0.0, 1.0))
+    ref = oracle.render(sc, want_bgra8=False)
+    res = mirhi.SceneResources(device, sc, want_prim=True, want_depth=want_depth)
+    for _ in range(2):                      # the second submission reuses the re-armed workspace
+        res.render()
+    out = res.read()
+    assert np.array_equal(out["prim"], ref["prim"])
+    assert np.abs(out["color"][..., :3] - ref["rgba"][..., :3]).max() < 1e-4
+    if want_depth:
+        assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+    res.destroy()
