@@ -10,7 +10,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit("missing " + pattern)
-    return hits[0]
+    return max(hits, key=os.path.getmtime)      # gpurun merges into gpurun_out/: earlier runs' files may still be there
 
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_c2_rocprofv3_kernel_stats.csv"))
 for name in ("bench_profile_pass", "bench_default"):
