@@ -452,7 +452,17 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
         const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
         if (!(o0 & o1 & o2)) {
             any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
-            if (any == 0) valid = setup_triangle(P, D, c, prim, t);
+            bool in_band = true;
+            if (any == 0 && (P.tile_row_begin != 0u || P.tile_row_end != P.tiles_y)) {
+                // tile-row split (one band per GPU): a triangle whose three vertices lie above the band, or below it, is
+                // dropped before the setup arithmetic -- every rank sees all triangles, most belong to other bands.
+                // Clip-space test with a one-pixel margin for the snap: ys = (y/w)*hh + cy, w > 0 here.
+                const float top = D.cy - ((float)(P.tile_row_begin * TILE) - 1.0f), bot = D.cy - ((float)(P.tile_row_end * TILE) + 1.0f);
+                const bool above = c[0].y * D.hh + top * c[0].w < 0.0f && c[1].y * D.hh + top * c[1].w < 0.0f && c[2].y * D.hh + top * c[2].w < 0.0f;
+                const bool below = c[0].y * D.hh + bot * c[0].w > 0.0f && c[1].y * D.hh + bot * c[1].w > 0.0f && c[2].y * D.hh + bot * c[2].w > 0.0f;
+                in_band = !(above || below) || !(c[0].w > 0.0f && c[1].w > 0.0f && c[2].w > 0.0f);
+            }
+            if (any == 0 && in_band) valid = setup_triangle(P, D, c, prim, t);
         }
     }
     if (P.flat_color && D.program == 0 && (valid || any)) {
