@@ -948,6 +948,13 @@ __device__ __forceinline__ int32_t step8(int32_t a, int32_t b) {
     return d;
 }
 
+// (a & mask) | (b & ~mask) in one instruction; the mask is wave-uniform
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
+
 template <int KEYED, bool BOXED>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
                                               float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
@@ -974,14 +981,17 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
         const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
         const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
         // clamp to [0,1]: v_med3_f32 returns min3 = 0 when z is NaN; the mask turns a -0 result into +0
-        uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+        const uint32_t zc = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f));
+        uint32_t zk;
         bool upd;
         if (KEYED == 0 && !BOXED) {
             // plain key: depth bits are <= 0x3F800000, so a lane outside the triangle can carry its miss in the key's
-            // top bit (such a key never beats a stored one) -- no separate compare, no mask AND
-            zk |= (uint32_t)sgn & 0x80000000u;             // (an updating lane has the bit clear: zk is stored unchanged)
+            // top bit (such a key never beats a stored one) -- no separate compare, no mask AND.  One bit-field insert
+            // takes the low 31 bits from the depth and the top bit from the edge functions' OR.
+            zk = bfi(0x7FFFFFFFu, zc, (uint32_t)sgn);      // (an updating lane has the bit clear: zk is stored unchanged)
             upd = (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
         } else {
+            zk = zc & 0x7FFFFFFFu;
             bool inside = sgn >= 0;
             if (BOXED) {
                 const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
