@@ -1,0 +1,397 @@
+// mirhi_geometry.hip.h -- vertex_kernel + geometry_kernel: fetch, vertex shader position, clip, setup, pair-parallel binning
+// Part of the single device translation unit mirhi_kernels.hip (included inside namespace mirhi).
+#ifndef MIRHI_GEOMETRY_HIP_H
+#define MIRHI_GEOMETRY_HIP_H
+
+// ------------------------------------------------------------------------------------------------
+// a1/a2/a4: index fetch, vertex fetch, vertex-shader position
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fetch_index(DrawRef D, uint32_t k) {
+    if (D.index_type == 0) return D.first + k;
+    uint32_t idx;
+    if (D.index_type == 2) idx = reinterpret_cast<const uint16_t*>(D.ib)[D.first + k];
+    else idx = reinterpret_cast<const uint32_t*>(D.ib)[D.first + k];
+    return (uint32_t)((int32_t)idx + D.vertex_offset);
+}
+
+__device__ __forceinline__ f4 vs_position(DrawRef D, uint32_t vidx, f3* world) {
+    const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+    f4 p = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};
+    if (D.program == 0) {                                   // vertex/triangle.hlsl:19
+        if (world) *world = {p.x, p.y, p.z};
+        return p;
+    }
+    f4 w = mat4_mul(cf(D.object), p);                       // vertex/model.hlsl:44
+    if (world) *world = {w.x, w.y, w.z};
+    return mat4_mul(cf(D.camera) + 32, w);                  // :48 (viewProjection @128 B)
+}
+
+// ------------------------------------------------------------------------------------------------
+// screen-space triangle record (TriRec, 48 B) and its tile-relative form (TileRec, 64 B, LDS only)
+// ------------------------------------------------------------------------------------------------
+struct ScreenTri {
+    int32_t X[3], Y[3];          // 1/256 px, orientation normalised (interior has E > 0)
+    float z0, zx, zy;
+    int32_t minx, maxx, miny, maxy;   // inclusive pixel bbox (scissor-clamped)
+    uint32_t idk, boxed;
+};
+
+__device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
+    dst[0] = make_uint4((uint32_t)t.X[0], (uint32_t)t.Y[0], (uint32_t)t.X[1], (uint32_t)t.Y[1]);
+    dst[1] = make_uint4((uint32_t)t.X[2], (uint32_t)t.Y[2], __float_as_uint(t.z0), __float_as_uint(t.zx));
+    dst[2] = make_uint4(__float_as_uint(t.zy), t.idk, (uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.boxed << 31),
+                        (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5: clip-space triangle (all w > 0) -> snapped, culled, oriented screen triangle + depth plane
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 c[3], uint32_t prim,
+                                               ScreenTri& t) {
+    float z[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (!(c[i].w > 0.0f)) return false;
+        const float iw = 1.0f / c[i].w;
+        const float xs = (c[i].x * iw) * D.hw + D.cx;                     // Vulkan viewport transform
+        const float ys = (c[i].y * iw) * D.hh + D.cy;
+        const float zs = (c[i].z * iw) * D.dscale + D.dmin;
+        if (!(fabsf(xs) <= 16383.0f) || !(fabsf(ys) <= 16383.0f)) return false;
+        t.X[i] = (int32_t)rintf(xs * 256.0f);                             // 8 sub-pixel bits, round-half-even
+        t.Y[i] = (int32_t)rintf(ys * 256.0f);
+        z[i] = zs;
+    }
+    const int64_t S = (int64_t)(t.X[1] - t.X[0]) * (int64_t)(t.Y[2] - t.Y[0]) -
+                      (int64_t)(t.X[2] - t.X[0]) * (int64_t)(t.Y[1] - t.Y[0]);
+    if (S == 0) return false;
+    const bool front = (D.front_face == 0) ? (S < 0) : (S > 0);           // Vulkan: a = -S/2, CCW front <=> a > 0
+    if (D.cull_mode == 3) return false;
+    if (D.cull_mode == 2 && !front) return false;
+    if (D.cull_mode == 1 && front) return false;
+    if (S < 0) {
+        int32_t ti = t.X[1]; t.X[1] = t.X[2]; t.X[2] = ti;
+        ti = t.Y[1]; t.Y[1] = t.Y[2]; t.Y[2] = ti;
+        float tz = z[1]; z[1] = z[2]; z[2] = tz;
+    }
+    const float inv256 = 1.0f / 256.0f;
+    const float fx1 = (float)(t.X[1] - t.X[0]) * inv256, fy1 = (float)(t.Y[1] - t.Y[0]) * inv256;
+    const float fx2 = (float)(t.X[2] - t.X[0]) * inv256, fy2 = (float)(t.Y[2] - t.Y[0]) * inv256;
+    const float area = fx1 * fy2 - fx2 * fy1;
+    const float dz1 = z[1] - z[0], dz2 = z[2] - z[0];
+    t.zx = (dz1 * fy2 - dz2 * fy1) / area;
+    t.zy = (dz2 * fx1 - dz1 * fx2) / area;
+    t.z0 = z[0];
+    const int32_t xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
+    const int32_t ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
+    int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
+    int32_t py0 = (ymin + 127) >> 8, py1 = (ymax - 128) >> 8;
+    const bool cut = D.scissor_partial && (px0 < D.sx0 || px1 > D.sx1 || py0 < D.sy0 || py1 > D.sy1);
+    px0 = max(px0, D.sx0); px1 = min(px1, D.sx1); py0 = max(py0, D.sy0); py1 = min(py1, D.sy1);
+    if (px0 > px1 || py0 > py1) return false;
+    // tile rows outside this device's band are not rasterized here (tile-row split)
+    const int32_t band0 = (int32_t)P.tile_row_begin * TILE, band1 = (int32_t)P.tile_row_end * TILE - 1;
+    if (py1 < band0 || py0 > band1) return false;
+    t.minx = px0; t.maxx = px1; t.miny = py0; t.maxy = py1;
+    t.boxed = cut ? 1u : 0u;
+    t.idk = P.idflip ? (MAX_PRIM_ID - prim) : prim;
+    return true;
+}
+
+__device__ __forceinline__ void emit_big(ParamsRef P, const ScreenTri& t) {
+    const uint32_t slot = atomicAdd(P.big_count, 1u);
+    if (slot < P.big_cap) store_tri(reinterpret_cast<uint4*>(P.big_recs) + (size_t)slot * 3u, t);
+    else __hip_atomic_fetch_or(P.status, STATUS_BIG_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// clip planes: near z>=0, far w-z>=0, guard band x,y within +-g*w (oracle: clip_polygon)
+__device__ __forceinline__ float plane_dist(int plane, f4 c, float gx, float gy) {
+    switch (plane) {
+        case 1: return c.z;
+        case 2: return c.w - c.z;
+        case 4: return c.x + gx * c.w;
+        case 8: return gx * c.w - c.x;
+        case 16: return c.y + gy * c.w;
+        default: return gy * c.w - c.y;
+    }
+}
+__device__ __forceinline__ uint32_t outcode_clip(f4 c, float gx, float gy) {
+    uint32_t oc = 0;
+    if (c.z < 0.0f) oc |= 1;
+    if (c.w - c.z < 0.0f) oc |= 2;
+    if (c.x + gx * c.w < 0.0f) oc |= 4;
+    if (gx * c.w - c.x < 0.0f) oc |= 8;
+    if (c.y + gy * c.w < 0.0f) oc |= 16;
+    if (gy * c.w - c.y < 0.0f) oc |= 32;
+    return oc;
+}
+__device__ __forceinline__ uint32_t outcode_view(f4 c) {
+    uint32_t oc = 0;
+    if (c.x < -c.w) oc |= 1; if (c.x > c.w) oc |= 2;
+    if (c.y < -c.w) oc |= 4; if (c.y > c.w) oc |= 8;
+    if (c.z < 0.0f) oc |= 16; if (c.z > c.w) oc |= 32;
+    return oc;
+}
+
+// Rare path: Sutherland-Hodgman in homogeneous space on a per-lane polygon in LDS (no scratch memory: a
+// kernel that touches scratch pays ~5 us per launch on this part).  Every resulting fan triangle goes to
+// the big list (the raster kernel builds its tile records), so this path needs no binning code.
+constexpr int CLIP_MAX_VERTS = 10;     // 3 + one per plane (near, far, 4 guard-band planes) = 9
+constexpr int CLIP_BATCH = 8;          // lanes clipping concurrently per wave (LDS polygon slots)
+
+__device__ __forceinline__ void clip_and_emit(ParamsRef P, DrawRef D, f4 (*poly)[CLIP_MAX_VERTS],
+                                              f4 c0, f4 c1, f4 c2, uint32_t any, uint32_t prim) {
+    f4* in = poly[0]; f4* tmp = poly[1];
+    in[0] = c0; in[1] = c1; in[2] = c2;
+    int n = 3;
+    for (int plane = 1; plane <= 32 && n >= 3; plane <<= 1) {
+        if (!(any & plane)) continue;
+        int m = 0;
+        for (int i = 0; i < n; i++) {
+            const f4 a = in[i], b = in[(i + 1) % n];
+            const float da = plane_dist(plane, a, D.gx, D.gy), db = plane_dist(plane, b, D.gx, D.gy);
+            const bool ina = da >= 0.0f, inb = db >= 0.0f;
+            if (ina) tmp[m++] = a;
+            if (ina != inb) {
+                f4 p, q; float dp, dq;
+                if (ina) { p = a; q = b; dp = da; dq = db; } else { p = b; q = a; dp = db; dq = da; }
+                const float tt = dp / (dp - dq);
+                tmp[m++] = {p.x + tt * (q.x - p.x), p.y + tt * (q.y - p.y), p.z + tt * (q.z - p.z), p.w + tt * (q.w - p.w)};
+            }
+        }
+        n = m;
+        f4* s = in; in = tmp; tmp = s;
+    }
+    for (int i = 1; i + 1 < n; i++) {
+        const f4 tri[3] = {in[0], in[i], in[i + 1]};
+        ScreenTri t;
+        if (setup_triangle(P, D, tri, prim, t)) emit_big(P, t);
+    }
+}
+
+__device__ __forceinline__ uint32_t find_draw(ParamsRef P, uint32_t prim) {
+    uint32_t lo = 0, hi = P.num_draws;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (const_draws(P.draws)[mid].prim_base <= prim) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: vertex-shader pre-pass for the MODEL / MODEL_FULL programs (vertex/model.hlsl:39-68)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* __restrict__ params) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
+    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    const MIRHI_CONST VsJob* jobs = (const MIRHI_CONST VsJob*)(uintptr_t)P.vs_jobs;
+    uint32_t lo = 0, hi = P.num_vs_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].slot_base <= slot0) lo = mid; else hi = mid;
+    }
+    const MIRHI_CONST VsJob& J = jobs[lo];
+    const uint32_t vidx = slot0 - J.slot_base + threadIdx.x;
+    if (vidx >= J.count) return;
+    const uint8_t* v = J.vb + (size_t)vidx * J.stride;
+    const CFloatPtr model = cf(J.object);
+    const f4 p = {ldf(v, 0), ldf(v, 4), ldf(v, 8), 1.0f};
+    const f4 w = mat4_mul(model, p);                                         // vertex/model.hlsl:44
+    const f4 c = mat4_mul(cf(J.camera) + 32, w);                             // :48
+    const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
+    const f3 N = normalize3(mat3_mul(model + 16, n));                        // :51
+    uint4* out = reinterpret_cast<uint4*>(J.out) + (size_t)vidx * J.words;
+    out[0] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
+    out[1] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(N.x));
+    out[2] = make_uint4(__float_as_uint(N.y), __float_as_uint(N.z), ldu(v, 24), ldu(v, 28));
+    if (J.words == 5) {
+        const f3 t = {ldf(v, 32), ldf(v, 36), ldf(v, 40)};
+        const float tw = ldf(v, 44);
+        f3 T = normalize3(mat3_mul(model, t));                               // :52
+        T = normalize3(sub3(T, scale3(N, dot3(T, N))));                      // :55 Gram-Schmidt
+        const f3 B = scale3(cross3(N, T), tw);                               // :58
+        out[3] = make_uint4(__float_as_uint(T.x), __float_as_uint(T.y), __float_as_uint(T.z), __float_as_uint(B.x));
+        out[4] = make_uint4(__float_as_uint(B.y), __float_as_uint(B.z), 0u, 0u);
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
+
+// Pair-parallel binning: the wave's (triangle, bin) pairs -- one per triangle for fine meshes, about five for scattered
+// 50-pixel triangles, sixteen at most -- are enumerated densely through LDS and dealt to the lanes 64 at a time, one
+// record copy per pair.  Every lane stays busy; a lane walking its own <= 16 bins (the first design) issued 2-3x the
+// instructions per wave, and sixteen lanes per triangle 10x (measured: C2 907 / 987 / 1089 Mtris/s for walk / wide / pairs).
+constexpr uint32_t PAIR_MAX = GEOM_THREADS * MAX_BIN_SPAN * MAX_BIN_SPAN;
+__device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
+                                                   uint32_t* lds_meta, uint16_t* lds_owner) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
+    bool spill = false;
+    if (valid) {
+        tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
+        ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
+        nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
+        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
+    }
+    const bool binned = valid && !spill;
+    const uint32_t nb = binned ? (uint32_t)(ntx * nty) : 0u;
+    // exclusive prefix sum of nb (<= 16) over the wave from five bit planes of ballots
+    uint32_t ex = 0, total = 0;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 5; bit++) {
+        const uint64_t m = __ballot(((nb >> bit) & 1u) != 0u);
+        ex += (uint32_t)__popcll(m & lt) << bit;
+        total += (uint32_t)__popcll(m) << bit;
+    }
+    if (binned) {
+        lds_tri[lane][0] = make_uint4((uint32_t)t.X[0], (uint32_t)t.Y[0], (uint32_t)t.X[1], (uint32_t)t.Y[1]);
+        lds_tri[lane][1] = make_uint4((uint32_t)t.X[2], (uint32_t)t.Y[2], __float_as_uint(t.z0), __float_as_uint(t.zx));
+        lds_tri[lane][2] = make_uint4(__float_as_uint(t.zy), t.idk, (uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.boxed << 31),
+                                      (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
+        lds_meta[lane] = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+        uint32_t pos = ex;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)(MAX_BIN_SPAN * MAX_BIN_SPAN); k++) {
+            if ((int32_t)(k % MAX_BIN_SPAN) < ntx && (int32_t)(k / MAX_BIN_SPAN) < nty) lds_owner[pos++] = (uint16_t)(lane | (k << 8));
+        }
+    }
+    __syncthreads();            // one wave per workgroup: orders the LDS writes above before the reads below
+    // All returning atomics of the wave are issued before the first result is consumed.  Lanes of a round that target
+    // the same tile (mesh order: most of them) are grouped and the group's first lane reserves the whole range with one
+    // atomic; grouping stops at the first small group (scattered input would only serialise its atomics).
+    constexpr uint32_t ROUNDS = PAIR_MAX / GEOM_THREADS;
+    constexpr int GROUP_ROUNDS = 8, GROUP_MIN = 2;
+    uint32_t raw[ROUNDS];      // atomic result (held by the reserving lane)
+    uint32_t who[ROUNDS];      // reserving lane | rank within its group << 8
+#pragma unroll
+    for (uint32_t it = 0; it < ROUNDS; it++) {
+        raw[it] = 0; who[it] = lane;
+        if (it * GEOM_THREADS >= total) break;
+        const uint32_t p = it * GEOM_THREADS + lane;
+        const bool act = p < total;
+        uint32_t tile = 0;
+        if (act) {
+            const uint32_t o = lds_owner[p], kk = o >> 8;
+            tile = lds_meta[o & 0xFFu] + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);   // (flag bit not set yet)
+        }
+        uint64_t rem = __ballot(act);
+        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+            const uint64_t grp = __ballot(act && tile == t0) & rem;
+            if (__popcll(grp) < GROUP_MIN) break;
+            if (act && tile == t0 && ((rem >> lane) & 1ull)) who[it] = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
+            if ((int)lane == leader) raw[it] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
+            rem &= ~grp;
+        }
+        if (act && ((rem >> lane) & 1ull)) raw[it] = atomicAdd(&P.bin_count[tile], 1u);   // ungrouped lanes
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < ROUNDS; it++) {
+        if (it * GEOM_THREADS >= total) break;
+        const uint32_t p = it * GEOM_THREADS + lane;
+        const uint32_t slot = (uint32_t)__shfl((int)raw[it], (int)(who[it] & 0xFFu)) + (who[it] >> 8);
+        if (p < total) {
+            const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
+            const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
+            if (slot < P.bin_cap) {
+                uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u;
+                dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
+            } else {
+                atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once
+            }
+        }
+    }
+    __syncthreads();
+    if (binned && (lds_meta[lane] >> 31)) spill = true;    // (idempotent resolve: being in some bins as well is harmless)
+    if (valid && spill) emit_big(P, t);
+}
+
+// One wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
+// and pipeline-state word) is wave-uniform and lives in SGPRs.  One lane per triangle up to the screen-space setup,
+// then bin_triangle_pairs.
+__global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
+    __shared__ f4 poly[CLIP_BATCH][2][CLIP_MAX_VERTS];   // 2.5 KB: clipping lanes take turns, 8 at a time
+    __shared__ uint4 lds_tri[GEOM_THREADS][3];
+    __shared__ uint32_t lds_meta[GEOM_THREADS];
+    __shared__ uint16_t lds_owner[PAIR_MAX];
+    GSTAMP(0);
+    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    uint32_t lo = 0, hi = H.num_draws;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (const_draws(H.draws)[mid].slot_base <= slot0) lo = mid; else hi = mid;
+    }
+    DrawRef D = const_draws(H.draws)[lo];
+    const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
+    const uint32_t prim = D.prim_base + tri;
+    bool valid = false;
+    uint32_t any = 0;
+    ScreenTri t;
+    f4 c[3];
+    bool dropped = false;
+    if (D.program == 3) {
+        // pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` decided per draw: alpha is
+        // baseColorFactor.a, or a texel alpha in [0,1] times it.  A draw whose texels could fall on both sides of
+        // the cutoff would need a per-fragment discard before the depth write: reported, not rendered.
+        const CBytePtr M = cb(D.material);
+        const float fa = ldcf(M, 12), cutoff = ldcf(M, 44);
+        float lo = fa, hi = fa;
+        if (ldcu(M, 48) != 0u) { lo = fa < 0.0f ? fa : 0.0f; hi = fa > 0.0f ? fa : 0.0f; }
+        if (hi < cutoff) dropped = true;
+        else if (!(lo >= cutoff)) {
+            dropped = true;
+            if (threadIdx.x == 0) __hip_atomic_fetch_or(P.status, STATUS_ALPHA_TEST_TEXTURED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (tri < D.tri_count && !dropped) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint32_t vidx = fetch_index(D, 3u * tri + k);
+            if (D.vs_words) {                      // MODEL programs: clip position from the vertex pre-pass
+                const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[(size_t)vidx * D.vs_words];
+                c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+            } else {
+                c[k] = vs_position(D, vidx, nullptr);
+            }
+        }
+        const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
+        if (!(o0 & o1 & o2)) {
+            any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
+            bool in_band = true;
+            if (any == 0 && (P.tile_row_begin != 0u || P.tile_row_end != P.tiles_y)) {
+                // tile-row split (one band per GPU): a triangle whose three vertices lie above the band, or below it, is
+                // dropped before the setup arithmetic -- every rank sees all triangles, most belong to other bands.
+                // Clip-space test with a one-pixel margin for the snap: ys = (y/w)*hh + cy, w > 0 here.
+                const float top = D.cy - ((float)(P.tile_row_begin * TILE) - 1.0f), bot = D.cy - ((float)(P.tile_row_end * TILE) + 1.0f);
+                const bool above = c[0].y * D.hh + top * c[0].w < 0.0f && c[1].y * D.hh + top * c[1].w < 0.0f && c[2].y * D.hh + top * c[2].w < 0.0f;
+                const bool below = c[0].y * D.hh + bot * c[0].w > 0.0f && c[1].y * D.hh + bot * c[1].w > 0.0f && c[2].y * D.hh + bot * c[2].w > 0.0f;
+                in_band = !(above || below) || !(c[0].w > 0.0f && c[1].w > 0.0f && c[2].w > 0.0f);
+            }
+            if (any == 0 && in_band) valid = setup_triangle(P, D, c, prim, t);
+        }
+    }
+    if (P.flat_color && D.program == 0 && (valid || any)) {
+        // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
+        const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
+        const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
+        const uint8_t* v2 = D.vb + (size_t)fetch_index(D, 3u * tri + 2u) * D.stride;
+        const uint32_t r = ldu(v0, 12), g = ldu(v0, 16), b = ldu(v0, 20);
+        const bool flat = r == ldu(v1, 12) && r == ldu(v2, 12) && g == ldu(v1, 16) && g == ldu(v2, 16) && b == ldu(v1, 20) && b == ldu(v2, 20);
+        P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
+    }
+    GSTAMP(1);
+    bin_triangle_pairs(P, valid, t, lds_tri, lds_meta, lds_owner);
+    GSTAMP(2);
+    uint64_t todo = __ballot(any != 0);
+    while (todo) {                                   // rare: triangles crossing the near / far / guard planes
+        const uint32_t rank = (uint32_t)__popcll(todo & ((1ull << (threadIdx.x & 63u)) - 1ull));
+        const bool mine = any != 0 && ((todo >> (threadIdx.x & 63u)) & 1ull) && rank < CLIP_BATCH;
+        if (mine) clip_and_emit(P, D, poly[rank], c[0], c[1], c[2], any, prim);
+        todo &= ~__ballot(mine);
+    }
+    GSTAMP(3);
+}
+
+#endif  // MIRHI_GEOMETRY_HIP_H

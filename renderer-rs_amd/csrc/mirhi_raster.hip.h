@@ -1,0 +1,517 @@
+// mirhi_raster.hip.h -- raster_kernel: tile records, coverage, depth key, resolve (rows a6, a7, a9)
+// Part of the single device translation unit mirhi_kernels.hip (included inside namespace mirhi).
+#ifndef MIRHI_RASTER_HIP_H
+#define MIRHI_RASTER_HIP_H
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// raster kernel
+// ------------------------------------------------------------------------------------------------
+struct PixelState { uint32_t zk[4], idk[4]; };   // (depth key, id key) per owned pixel; lexicographic minimum wins
+struct RecRegs { uint4 w0, w1, w2, w3; };
+
+__device__ __forceinline__ RecRegs load_rec(const uint4* lds_rec, uint32_t j) {
+    RecRegs r;
+    r.w0 = lds_rec[j * 4u + 0]; r.w1 = lds_rec[j * 4u + 1]; r.w2 = lds_rec[j * 4u + 2]; r.w3 = lds_rec[j * 4u + 3];
+    return r;
+}
+
+// d = a * b + c with 24-bit signed a, b (full-rate integer multiply-add)
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// 48-bit product of two signed 24-bit values
+__device__ __forceinline__ int64_t mul24x24(int32_t a, int32_t b) {
+    const uint32_t lo = (uint32_t)__mul24(a, b);     // low 32 bits of the product (operands fit 24 bits)
+    const int32_t hi = __mulhi(a, b);                // high 32 bits of the 64-bit product
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | lo);
+}
+
+// TriRec (screen space) -> TileRec for tile (tx, ty); false if no 8x8 block of the tile can be touched.
+//   w0 = { Q0, Q1, Q2, A0 }   Q_i = floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
+//   w1 = { A1, A2, B0, B1 }   A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23, fits v_mad_i32_i24)
+//   w2 = { B2, dxt, dyt, z0 } (tile origin pixel centre) - (snapped vertex 0), in pixels (exact), vertex-0 depth
+//   w3 = { zx, zy, idk, mask } mask bits 0..15 = 8x8 blocks the triangle may touch, bit 31 = pixel box applies
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2,
+                                              int32_t tx, int32_t ty) {
+    const int32_t X[3] = {(int32_t)w0.x, (int32_t)w0.z, (int32_t)w1.x}, Y[3] = {(int32_t)w0.y, (int32_t)w0.w, (int32_t)w1.y};
+    const int32_t ox = tx * TILE, oy = ty * TILE;
+    const int32_t Ptx = 256 * ox + 128, Pty = 256 * oy + 128;           // tile origin pixel centre, 1/256 px
+    int32_t A[3], B[3], Q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int a = i, b = (i + 1) % 3;
+        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
+        A[i] = -dy; B[i] = dx;
+        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
+        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22, |Pt| < 2^21)
+        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
+        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
+        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
+        Q[i] = (int32_t)q;
+    }
+    int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - ox, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - ox;
+    int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - oy, by1 = (int32_t)(w2.w >> 16) - oy;
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
+    // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
+    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
+    // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
+    // block -- no compares, no branches, nothing on the scalar unit.
+    int32_t c[3], a8[3], b8[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
+        a8[i] = A[i] * BLOCK; b8[i] = B[i] * BLOCK;
+    }
+    uint32_t outside = 0;                               // after the loop: bit (15 - (by*4+bx)) set <=> block outside an edge
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+        int32_t v0 = c[0], v1 = c[1], v2 = c[2];
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) {
+            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)(v0 | v1 | v2), 31);   // (outside << 1) | sign
+            v0 += a8[0]; v1 += a8[1]; v2 += a8[2];
+        }
+        c[0] += b8[0]; c[1] += b8[1]; c[2] += b8[2];
+    }
+    // pixel box -> block box -> mask of the blocks inside it (4 column bits replicated per row, row bits spread to nibbles)
+    const uint32_t cols = ((2u << ((uint32_t)bx1 >> 3)) - 1u) & ~((1u << ((uint32_t)bx0 >> 3)) - 1u);          // bits bx0b..bx1b
+    const uint32_t rows = ((2u << ((uint32_t)by1 >> 3)) - 1u) & ~((1u << ((uint32_t)by0 >> 3)) - 1u);
+    const uint32_t rowsel = ((rows & 1u) * 0xFu) | ((rows & 2u) * 0x78u) | ((rows & 4u) * 0x3C0u) | ((rows & 8u) * 0x1E00u);
+    const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
+    const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
+    const float inv256 = 1.0f / 256.0f;
+    const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
+    const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
+    out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
+    out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
+    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), w1.z);
+    out[3] = make_uint4(w1.w, w2.x, w2.y, mask | (w2.z & 0x80000000u));
+    box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+    return mask != 0;
+}
+
+// coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
+// KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied);
+//         2: predicate against the scope's initial depth (see DESIGN.md "Depth key").
+// d = (a << 3) + b in one instruction (8 = BLOCK: the step of an edge function from one 8x8 block to the next)
+__device__ __forceinline__ int32_t step8(int32_t a, int32_t b) {
+    int32_t d;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// (a & mask) | (b & ~mask) in one instruction; the mask is wave-uniform
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
+
+template <int KEYED, bool BOXED>
+__device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
+                                              float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
+    const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
+    const int32_t B0 = (int32_t)r.w1.z, B1 = (int32_t)r.w1.w, B2 = (int32_t)r.w2.x;
+    const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
+    const uint32_t idk = r.w3.z;
+    const uint32_t m = __builtin_amdgcn_readfirstlane(r.w3.w);
+    const int32_t s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)r.w0.x));
+    const int32_t s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)r.w0.y));
+    const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
+    // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
+    const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int bx = b & 1, by = b >> 1;
+        if (!(m & (qbit0 << (by * 4 + bx)))) continue;
+        // edge functions at this block: one shift-add per edge and step (v_lshl_add_u32), no shared shift results
+        int32_t sgn;                                         // covered <=> sign bit clear
+        if (!bx && !by) sgn = s0 | s1 | s2;
+        else if (bx && !by) sgn = step8(A0, s0) | step8(A1, s1) | step8(A2, s2);
+        else if (!bx && by) sgn = step8(B0, s0) | step8(B1, s1) | step8(B2, s2);
+        else sgn = step8(B0, step8(A0, s0)) | step8(B1, step8(A1, s1)) | step8(B2, step8(A2, s2));
+        const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
+        const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+        // clamp to [0,1]: v_med3_f32 returns min3 = 0 when z is NaN; the mask turns a -0 result into +0
+        const uint32_t zc = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f));
+        uint32_t zk;
+        bool upd;
+        if (KEYED == 0 && !BOXED) {
+            // plain key: depth bits are <= 0x3F800000, so a lane outside the triangle can carry its miss in the key's
+            // top bit (such a key never beats a stored one) -- no separate compare, no mask AND.  One bit-field insert
+            // takes the low 31 bits from the depth and the top bit from the edge functions' OR.
+            zk = bfi(0x7FFFFFFFu, zc, (uint32_t)sgn);      // (an updating lane has the bit clear: zk is stored unchanged)
+            upd = (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+        } else {
+            zk = zc & 0x7FFFFFFFu;
+            bool inside = sgn >= 0;
+            if (BOXED) {
+                const int32_t ix = ix0 + bx * BLOCK, iy = iy0 + by * BLOCK;
+                inside = inside && ix >= (int32_t)(box & 0xFF) && ix <= (int32_t)((box >> 8) & 0xFF) &&
+                         iy >= (int32_t)((box >> 16) & 0xFF) && iy <= (int32_t)(box >> 24);
+            }
+            if (KEYED == 2) {
+                // predicate mode (depth test without write, EQUAL, ALWAYS with write): the fragment is tested against the
+                // depth the scope started with (kept in st.zk), the latest passing primitive wins (idk = MAX - id)
+                const uint32_t pred = P.pred;
+                const bool lt = zk < st.zk[b], eq = zk == st.zk[b];
+                const bool pass = (lt && (pred & 1u)) || (eq && (pred & 2u)) || (!lt && !eq && (pred & 4u));
+                upd = inside && pass && idk < st.idk[b];
+                if (!(pred & 8u)) zk = st.zk[b];           // only ALWAYS-with-write replaces the depth (by the winner's)
+            } else {
+                if (KEYED) zk = (zk ^ P.zflip) & P.zmask;
+                upd = inside && (((uint64_t)zk << 32) | idk) < (((uint64_t)st.zk[b] << 32) | st.idk[b]);
+            }
+        }
+        st.zk[b] = upd ? zk : st.zk[b];
+        st.idk[b] = upd ? idk : st.idk[b];
+    }
+}
+
+// all records of an LDS chunk: per 64 records one ballot builds the bitmap of records that touch this
+// wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
+template <int KEYED, int TP>
+__device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
+                                             int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
+                                             PixelState& st, uint32_t qbit0, uint32_t lane) {
+    for (uint32_t g = 0; g < n; g += 64u) {
+        const uint32_t j = g + lane;
+        const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
+        const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u;
+        uint64_t bits = __ballot(rel && !boxed);
+        while (bits) {
+            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
+            bits &= bits - 1;
+            const RecRegs cur = load_rec(lds_rec, cur_j);
+            raster_record<KEYED, false>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
+        }
+        if (!TP) {   // without the triangle-parallel path, scissor-cut triangles (rare) take the per-pixel box test here
+            uint64_t bbits = __ballot(rel && boxed);
+            while (bbits) {
+                const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bbits) - 1);
+                bbits &= bbits - 1;
+                const RecRegs cur = load_rec(lds_rec, cur_j);
+                raster_record<KEYED, true>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
+            }
+        }
+    }
+}
+
+// Triangle-parallel resolve of ONE small record by the lane that built it: walks the record's pixel box inside the
+// tile and merges covered pixels into the tile's LDS key array with 64-bit ds_min.  For tiles holding many small
+// triangles this keeps all 64 lanes busy on different triangles, where the pixel-parallel loop above would spend a
+// full wave iteration per triangle with a handful of lanes covered.  Same integers, same depth FMAs, same keys.
+template <int KEYED>
+__device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, unsigned long long* lds_key, ParamsRef P) {
+    const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
+    const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
+    const float dxt = __uint_as_float(rec[2].y), dyt = __uint_as_float(rec[2].z), z0 = __uint_as_float(rec[2].w);
+    const float zx = __uint_as_float(rec[3].x), zy = __uint_as_float(rec[3].y);
+    const uint32_t idk = rec[3].z;
+    const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
+    const int32_t by0 = (int32_t)((box >> 16) & 0xFF), by1 = (int32_t)(box >> 24);
+    int32_t r0 = mad24(B0, by0, mad24(A0, bx0, (int32_t)rec[0].x));
+    int32_t r1 = mad24(B1, by0, mad24(A1, bx0, (int32_t)rec[0].y));
+    int32_t r2 = mad24(B2, by0, mad24(A2, bx0, (int32_t)rec[0].z));
+    for (int32_t iy = by0; iy <= by1; iy++) {
+        int32_t s0 = r0, s1 = r1, s2 = r2;
+        const float dy = (float)iy + dyt;
+        for (int32_t ix = bx0; ix <= bx1; ix++) {
+            if ((s0 | s1 | s2) >= 0) {
+                const float dx = (float)ix + dxt;
+                const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+                uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+                if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
+                atomicMin(&lds_key[iy * TILE + ix], ((unsigned long long)zk << 32) | idk);
+            }
+            s0 += A0; s1 += A1; s2 += A2;
+        }
+        r0 += B0; r1 += B1; r2 += B2;
+    }
+}
+
+__device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, bool valid, uint32_t& zk,
+                                         uint32_t& idk, uint32_t& zorig) {
+    zk = P.init_zk; idk = P.init_idk; zorig = P.clear_depth_bits;
+    if (P.depth_load && P.depth && valid) {
+        const uint32_t bits = __float_as_uint(P.depth[(size_t)py * P.width + px]);
+        zorig = bits;
+        if (P.zmask) {
+            const uint32_t t = bits ^ P.zflip;
+            if (!P.strict) { zk = t; idk = NO_PRIM; }
+            else if (t == 0u) { zk = 0u; idk = 0u; }
+            else { zk = t - 1u; idk = NO_PRIM; }
+        }
+    }
+}
+
+// Stages up to RASTER_THREADS triangle records of `list` (bin or big list) into LDS as tile records
+// (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
+template <int KEYED, int TP>
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
+                                            uint32_t* lds_count, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
+                                            uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
+                                            ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
+                                            uint32_t lane) {
+    const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
+    // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
+    // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
+    const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
+    for (uint32_t base = 0; base < n_total; base += RASTER_CHUNK) {
+        if (tid == 0) *lds_count = 0;
+        __syncthreads();
+        // opaque copies: what make_tile_rec derives from the tile coordinates is rebuilt per chunk (a few instructions)
+        // instead of being hoisted out of the loops into VGPRs that then spill
+        uint32_t txl = tx, tyl = ty;
+        asm volatile("" : "+s"(txl), "+s"(tyl));
+        const uint32_t i = base + ftid;
+        bool hit = false;
+        uint4 rec[4]; uint32_t box = 0;
+        if (ftid < RASTER_CHUNK && i < n_total) {
+            // all three words are requested together: one memory round trip, not two (a bin holds only records whose
+            // box overlaps the tile, so the box test below almost never saves the first two loads)
+            const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
+            const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
+            const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
+            hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
+            if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
+        }
+        bool small = false, boxed = false;
+        if (hit) {
+            // small (and all scissor-cut) records are resolved right here, triangle-parallel; the rest is staged
+            const uint32_t bw = ((box >> 8) & 0xFF) - (box & 0xFF) + 1u, bh = (box >> 24) - ((box >> 16) & 0xFF) + 1u;
+            small = bw * bh <= P.tp_max_area;
+            boxed = (rec[3].w & 0x80000000u) != 0u;
+        }
+        // Triangle-parallel only pays when the wave holds enough small records to keep its lanes busy (meshes of small
+        // triangles); a few stragglers in a sparse tile would serialise their pixel loops while 3 waves wait.
+        if (TP) {
+            const bool wave_tp = __popcll(__ballot(hit && small)) >= TP_MIN_LANES;
+            if (hit && (boxed || (small && wave_tp))) {
+                raster_small<KEYED>(rec, box, lds_key, P);
+                hit = false;
+            }
+        }
+        const uint64_t ball = __ballot(hit);
+        uint32_t wbase = 0;
+        if (lane == 0 && ball) wbase = atomicAdd(lds_count, (uint32_t)__popcll(ball));
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (hit) {
+            const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+            lds_rec[slot * 4u + 0] = rec[0]; lds_rec[slot * 4u + 1] = rec[1];
+            lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
+            if (!TP) lds_box[slot] = box;
+        }
+        __syncthreads();
+        const uint32_t n = *lds_count;
+        if (base == 0) { STAMP(5); STAGE_END(2u); }
+        if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
+    }
+}
+
+// PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws; 4 = any mix that
+// includes MODEL_PBR draws (its own variant so that the Cook-Torrance code costs the other variants no registers)
+// TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
+//     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
+template <int PROGS, int KEYED, int TP>
+__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+    ParamsRef P = *(ParamsPtr)(uintptr_t)params;
+    __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
+    __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
+    __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
+    __shared__ uint32_t lds_count;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
+    // (one contiguous band of tiles per XCD measured 20-30 % slower on unevenly covered frames: runs stay interleaved)
+    // Plain order: a 2-D grid, (blockIdx.x, blockIdx.y) = (tile column, tile row of the band): no division.
+    // P.xcd_swizzle > 1 (1-D grid): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, each XCD
+    // has its own L2); runs of G consecutive tiles go to the same XCD so neighbouring tiles hit the same L2.
+    uint32_t tx = blockIdx.x, tyr = blockIdx.y;
+    if (gridDim.y == 1u && P.xcd_swizzle > 1u) {
+        const uint32_t G = P.xcd_swizzle, ntiles = gridDim.x;
+        uint32_t t = blockIdx.x;
+        if (ntiles % (8u * G) == 0u) {
+            const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+            t = ((j / G) * 8u + xcd) * G + (j % G);
+        }
+        tx = t % H.tiles_x; tyr = t / H.tiles_x;
+    }
+    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
+    const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
+    const float fix0 = (float)ix0, fiy0 = (float)iy0;
+    // the four 8x8 blocks of quadrant q are bits (2*(q>>1)+by)*4 + 2*(q&1)+bx of the record's block mask
+    const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
+    const uint32_t qmask = qbit0 * 0x33u;
+
+    STAMP(0);
+    // both counters are fetched up front so their latencies overlap
+    // (the head of the parameters comes by value: the counter loads depend on the kernarg load alone, not on a second hop)
+    const uint32_t count_raw = H.bin_count[tile];
+    const uint32_t nbig_raw = *H.big_count;
+    const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
+    const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
+    // The big-list counters are re-armed right away (no workgroup reads the other parity's counter, and the next scope
+    // that uses this workspace is ordered behind this kernel), so nbig_raw need not stay live across the raster loops.
+    // The tile's own bin counter is re-armed after the bin pass: every wave of this workgroup reads it above, and the
+    // barriers of that pass order those reads before the store.
+    if (tid == 0 && tile == 0) {
+        *P.big_count_next = 0;                              // the next scope on this workspace appends to the other counter
+        P.status[1] = nbig_raw;
+    }
+
+    if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
+    PixelState st;
+#pragma unroll
+    for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
+    if (P.depth_load && P.depth) {              // second scope on a kept depth buffer: keys start from the stored depth
+        const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+            uint32_t zo;
+            init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
+        }
+    }
+
+    STAMP(1);
+    STAGE_END(1u);
+    // the tile's bin, then the list every tile tests (large / clipped / spilled triangles): one copy of the code
+    const uint4* list = reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u;
+    uint32_t n_list = count;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (n_list) raster_list<KEYED, TP>(list, n_list, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+                                           qbit0, tid, lane);
+        if (pass == 0) {
+            STAMP(2);
+            if (count && tid == 0) H.bin_count[tile] = 0;   // ready for the next scope that uses this workspace
+            if (!nbig) break;
+            // parameters of this phase are (re)read here, see launder_params
+            list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);
+            n_list = nbig;
+        }
+    }
+
+    STAMP(3);
+    STAGE_END(3u);
+    if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
+    // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
+    // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
+    if (TP) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long kreg = ((unsigned long long)st.zk[b] << 32) | st.idk[b];
+            const unsigned long long klds = lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK];
+            const unsigned long long kmin = klds < kreg ? klds : kreg;
+            st.zk[b] = (uint32_t)(kmin >> 32); st.idk[b] = (uint32_t)kmin;
+        }
+    }
+    // The resolve reads its parameters through a laundered kernarg pointer: the scalar loads are issued here, not at
+    // kernel entry, so their registers are not live across the raster loops (which otherwise spill SGPRs to VGPR lanes).
+    const ParamsPtr R = launder_params((ParamsPtr)(uintptr_t)params);
+    const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
+    // flat colours of all four owned pixels are requested before the first one is used (four overlapping loads
+    // instead of four dependent round trips in the loop below).  A pixel is covered iff its id key moved off the
+    // initial one (no primitive carries NO_PRIM, and the "nothing can pass" state (0, 0) is never replaced).
+    // Addressing is a uniform base plus a 32-bit byte offset per lane (tables and targets stay far below 4 GB).
+    uint32_t flat4[4] = {0u, 0u, 0u, 0u};
+    const uint8_t* flat_color = PROGS == 1 && !R->depth_load ? reinterpret_cast<const uint8_t*>(R->flat_color) : nullptr;
+    const uint32_t init_idk = R->init_idk;
+    if (flat_color) {
+        if (R->idflip) {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (st.idk[b] != init_idk) flat4[b] = *reinterpret_cast<const uint32_t*>(flat_color + ((MAX_PRIM_ID - st.idk[b]) << 2));
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (st.idk[b] != init_idk) flat4[b] = *reinterpret_cast<const uint32_t*>(flat_color + (st.idk[b] << 2));
+        }
+    }
+    // Fast exit for the headline shape of work: every covered pixel of this wave belongs to a flat-coloured
+    // triangle whose packed colour the geometry kernel already produced, and only the 8-bit colour target is
+    // written.  Same values as the general loop below, a fraction of its instructions.
+    if (flat_color && R->color_format != 2 && !R->prim_out && !(R->depth && R->depth_store)) {
+        // a covered pixel without a flat colour has to be shaded: then the whole wave takes the general loop
+        const bool need_shade = (st.idk[0] != init_idk && flat4[0] == 0u) || (st.idk[1] != init_idk && flat4[1] == 0u) ||
+                                (st.idk[2] != init_idk && flat4[2] == 0u) || (st.idk[3] != init_idk && flat4[3] == 0u);
+        if (__ballot(need_shade) == 0ull) {
+            const uint32_t width = R->width, height = R->height, clear_packed = R->clear_packed;
+            uint8_t* row0 = reinterpret_cast<uint8_t*>(R->color);
+            uint8_t* row1 = row0 + (size_t)BLOCK * width * 4u;                 // the lower pair of blocks: uniform base
+            const uint32_t off = (py0 * width + px0) * 4u;
+            if ((tx + 1u) * TILE <= width && (ty + 1u) * TILE <= height && !R->color_load) {   // wave-uniform: interior tile
+                *reinterpret_cast<uint32_t*>(row0 + off) = st.idk[0] != init_idk ? flat4[0] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row0 + off + 4u * BLOCK) = st.idk[1] != init_idk ? flat4[1] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row1 + off) = st.idk[2] != init_idk ? flat4[2] : clear_packed;
+                *reinterpret_cast<uint32_t*>(row1 + off + 4u * BLOCK) = st.idk[3] != init_idk ? flat4[3] : clear_packed;
+            } else {
+                const uint32_t color_load = R->color_load;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+                    const bool won = st.idk[b] != init_idk;
+                    if (px < width && py < height && (won || !color_load))
+                        *reinterpret_cast<uint32_t*>((b >> 1 ? row1 : row0) + off + 4u * BLOCK * (uint32_t)(b & 1)) = won ? flat4[b] : clear_packed;
+                }
+            }
+            STAMP(4);
+            return;
+        }
+    }
+#pragma unroll 1
+    for (int b = 0; b < 4; b++) {
+        const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+        const bool inb = px < P.width && py < P.height;
+        uint32_t izk, iidk, zorig;
+        init_key(P, px, py, inb, izk, iidk, zorig);
+        const uint32_t zkb = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
+        const uint32_t idb = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
+        const bool none = !inb || ((zkb == izk) && (idb == iidk));
+        const size_t pix = (size_t)py * P.width + px;
+        const uint32_t prim = none ? NO_PRIM : (P.idflip ? (MAX_PRIM_ID - idb) : idb);
+        f4 col = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
+        // waterfall over the draws present in this wave: the draw descriptor stays wave-uniform (scalar loads)
+        const uint32_t mydraw = none ? 0xFFFFFFFFu : (P.num_draws > 1 ? find_draw(P, prim) : 0u);
+        uint32_t flat = 0;
+        if (PROGS == 1 && P.flat_color && !none) {      // alpha is 255 whenever it is set
+            if (P.depth_load) flat = P.flat_color[prim];
+            else flat = b == 0 ? flat4[0] : (b == 1 ? flat4[1] : (b == 2 ? flat4[2] : flat4[3]));
+        }
+        uint64_t todo = __ballot(!none && flat == 0u);
+        while (todo) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);
+            const bool mine = mydraw == d && flat == 0u;
+            if (mine) {
+                // readfirstlane again: inside this branch the compiler knows mydraw == d and would otherwise
+                // substitute the per-lane value, turning every descriptor access into a vector load
+                DrawRef D = const_draws(P.draws)[__builtin_amdgcn_readfirstlane(mydraw)];
+                const uint32_t tri = prim - D.prim_base;
+                const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
+                if (PROGS == 1) col = shade_triangle_program(D, tri, pxc, pyc);
+                else if (PROGS == 2) col = shade_model_program<false>(D, tri, pxc, pyc);
+                else col = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program<PROGS == 4>(D, tri, pxc, pyc);
+            }
+            todo &= ~__ballot(mine);
+        }
+        if (!inb) continue;
+        if (!(none && P.color_load)) {
+            if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
+            else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));
+        }
+        if (P.prim_out && !(none && P.color_load)) P.prim_out[pix] = prim;     // LOAD keeps what an earlier scope / segment wrote
+        if (P.depth && P.depth_store) {
+            const uint32_t zb = (none || !P.zmask) ? zorig : (zkb ^ P.zflip);
+            P.depth[pix] = __uint_as_float(zb);
+        }
+    }
+    STAMP(4);
+}
+
+#endif  // MIRHI_RASTER_HIP_H

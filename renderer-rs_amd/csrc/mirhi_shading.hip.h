@@ -1,0 +1,364 @@
+// mirhi_shading.hip.h -- fragment programs: TRIANGLE, MODEL, MODEL_FULL, MODEL_PBR; texture sampling; sRGB pack (rows a8, a9)
+// Part of the single device translation unit mirhi_kernels.hip (included inside namespace mirhi).
+#ifndef MIRHI_SHADING_HIP_H
+#define MIRHI_SHADING_HIP_H
+
+// ------------------------------------------------------------------------------------------------
+// a8: fragment programs.  Colour is tolerance-checked (|dRGB| < 1e-4 vs the oracle), not bit-exact, so
+// this part may contract to FMA and use the 1-ulp hardware rcp / rsq / exp2 / log2.
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// pow(x, y) for x >= 0 as exp2(y * log2(x)) (HLSL pow lowering); pow(0, y>0) = 0
+// log2 near 1 comes from the series of ln(1+t) (t = x-1 is exact there): the hardware v_log_f32 has an absolute
+// error of ~2^-22 around 1, which a Blinn-Phong exponent of up to 2048 would amplify past the 1e-4 colour bound.
+__device__ __forceinline__ float flog2(float x) {
+    const float t = x - 1.0f;
+    const float p = t * (1.0f + t * (-0.5f + t * (0.33333334f + t * (-0.25f + t * 0.2f))));
+    return fabsf(t) < 0.015625f ? p * 1.44269504089f : __builtin_amdgcn_logf(x);
+}
+__device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgcn_exp2f(y * flog2(x)); }
+__device__ __forceinline__ f3 fnormalize3(f3 a) { const float r = frsq(dot3(a, a)); return {a.x * r, a.y * r, a.z * r}; }
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float attenuation(float distance, float radius) {          // lights.hlsli:63-73
+    const float att = 1.0f / (distance * distance + 1.0f);
+    float falloff = saturatef(1.0f - distance / radius);
+    falloff = falloff * falloff;
+    return att * falloff;
+}
+__device__ __forceinline__ float roughness_to_shininess(float roughness) {             // lights.hlsli:152-159
+    const float r = roughness < 0.0f ? 0.0f : (roughness > 1.0f ? 1.0f : roughness);
+    return 2048.0f + (2.0f - 2048.0f) * r;
+}
+__device__ __forceinline__ f3 blinn_phong(f3 L, f3 V, f3 N, f3 lightColor, f3 albedo, float shininess) {  // :95-117
+    float NdotL = dot3(N, L);
+    if (!(NdotL > 0.0f)) NdotL = 0.0f;
+    const f3 diffuse = mul3(scale3(lightColor, NdotL), albedo);
+    if (NdotL <= 0.0f) return diffuse;
+    const f3 H = normalize3(add3(L, V));
+    float NdotH = dot3(N, H);
+    if (!(NdotH > 0.0f)) NdotH = 0.0f;
+    const float sp = fpow(NdotH, shininess);
+    return add3(diffuse, scale3(lightColor, sp));
+}
+
+__device__ __forceinline__ f4 unpack_rgba8(uint32_t p) {
+    const float s = 1.0f / 255.0f;
+    return {(float)(p & 0xFF) * s, (float)((p >> 8) & 0xFF) * s, (float)((p >> 16) & 0xFF) * s, (float)(p >> 24) * s};
+}
+// repeat addressing of one coordinate: c mod n into [0, n); a mask when n is a power of two (the usual case),
+// one division otherwise.  The +1 neighbour wraps by comparison, so a bilinear tap costs two of these, not eight.
+__device__ __forceinline__ int32_t wrap_coord(int32_t c, int32_t n) {
+    if ((n & (n - 1)) == 0) return c & (n - 1);          // n is wave-uniform: a scalar branch
+    c %= n;
+    return c < 0 ? c + n : c;
+}
+// bilinear, repeat, no mips (see oracle sample_bilinear)
+__device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, uint32_t h, float u, float v) {
+    if (!tex || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
+    const uint32_t* texels = reinterpret_cast<const uint32_t*>(tex);
+    if (w == 1 && h == 1) return unpack_rgba8(texels[0]);
+    const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float ax = fx - x0f, ay = fy - y0f;
+    const int32_t x0 = wrap_coord((int32_t)x0f, (int32_t)w), y0 = wrap_coord((int32_t)y0f, (int32_t)h);
+    const int32_t x1 = x0 + 1 == (int32_t)w ? 0 : x0 + 1, y1 = y0 + 1 == (int32_t)h ? 0 : y0 + 1;
+    const uint32_t r0 = (uint32_t)y0 * w, r1 = (uint32_t)y1 * w;
+    const f4 c00 = unpack_rgba8(texels[r0 + (uint32_t)x0]), c10 = unpack_rgba8(texels[r0 + (uint32_t)x1]);
+    const f4 c01 = unpack_rgba8(texels[r1 + (uint32_t)x0]), c11 = unpack_rgba8(texels[r1 + (uint32_t)x1]);
+    f4 r;
+#define MIRHI_LERP2(f) { const float top = c00.f + (c10.f - c00.f) * ax; const float bot = c01.f + (c11.f - c01.f) * ax; r.f = top + (bot - top) * ay; }
+    MIRHI_LERP2(x) MIRHI_LERP2(y) MIRHI_LERP2(z) MIRHI_LERP2(w)
+#undef MIRHI_LERP2
+    return r;
+}
+
+#pragma clang fp contract(off)
+// Everything that feeds pow(NdotH, shininess) must match the oracle bit for bit: an exponent of up to 2048
+// turns a 1-ulp difference in NdotH into a 1e-4 relative difference of the specular term.
+struct Varyings { f3 world, normal, tangent, bitangent; float u, v; };
+
+__device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
+    return {(b[0] * a0.x + b[1] * a1.x) + b[2] * a2.x, (b[0] * a0.y + b[1] * a1.y) + b[2] * a2.y,
+            (b[0] * a0.z + b[1] * a1.z) + b[2] * a2.z};
+}
+
+// perspective-correct barycentrics of the pixel centre from the original clip-space triangle
+// (2-D homogeneous form relative to the pixel: valid for w <= 0 vertices, no clipped attributes needed)
+template <bool FAST>
+__device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc, float pyc, float b[3]) {
+    float ax[3], ay[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        ax[k] = (c[k].x * D.hw + c[k].w * D.cx) - pxc * c[k].w;
+        ay[k] = (c[k].y * D.hh + c[k].w * D.cy) - pyc * c[k].w;
+    }
+    const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
+    const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
+    const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
+    const float inv = FAST ? __builtin_amdgcn_rcpf((l0 + l1) + l2) : 1.0f / ((l0 + l1) + l2);
+    b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
+}
+
+#pragma clang fp contract(fast)
+// vertex/triangle.hlsl + pixel/triangle.hlsl: clip = (pos, 1), colour pass-through.  No pow downstream, so FMA
+// contraction and the 1-ulp rcp stay ~1e-7 from the oracle (bound 1e-4).  With w = 1 the homogeneous
+// barycentrics reduce to ax_k = x_k * W/2 + (cx - px).
+__device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
+    float ax[3], ay[3]; f3 col[3];
+    const float tx = D.cx - pxc, ty = D.cy - pyc;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t vidx = fetch_index(D, 3u * tri + k);
+        const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+        ax[k] = ldf(v, 0) * D.hw + tx;                                       // vertex/triangle.hlsl:19-20
+        ay[k] = ldf(v, 4) * D.hh + ty;
+        col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
+    }
+    const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
+    const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
+    const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
+    const float inv = __builtin_amdgcn_rcpf((l0 + l1) + l2);
+    const float b[3] = {l0 * inv, l1 * inv, l2 * inv};
+    const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
+    return {o.x, o.y, o.z, 1.0f};
+}
+#pragma clang fp contract(off)
+
+// a8: Cook-Torrance GGX, shaders/hlsl/pbr.hlsli (shadow pass not on the path: shadow = 1)
+#define PBR_PI 3.14159265358979323846f
+#define PBR_EPSILON 0.0001f
+__device__ __forceinline__ float max0(float x) { return x > 0.0f ? x : 0.0f; }
+__device__ __forceinline__ float distribution_ggx(float NdotH, float roughness) {       // pbr.hlsli:55-69
+    const float a = roughness * roughness, a2 = a * a;
+    const float NdotH2 = NdotH * NdotH;
+    float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
+    denom = (PBR_PI * denom) * denom;
+    return a2 / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+__device__ __forceinline__ float geometry_schlick_ggx(float NdotV, float roughness) {   // pbr.hlsli:83-93
+    const float r = roughness + 1.0f;
+    const float k = (r * r) / 8.0f;
+    const float denom = NdotV * (1.0f - k) + k;
+    return NdotV / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+}
+struct PbrMaterial { f3 albedo; float metallic, roughness; };
+__device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const PbrMaterial& m) {   // pbr.hlsli:292-333
+    const f3 H = normalize3(add3(V, L));
+    const f3 F0 = {0.04f + (m.albedo.x - 0.04f) * m.metallic, 0.04f + (m.albedo.y - 0.04f) * m.metallic,
+                   0.04f + (m.albedo.z - 0.04f) * m.metallic};
+    const float NDF = distribution_ggx(max0(dot3(N, H)), m.roughness);
+    const float NdotV = max0(dot3(N, V)), NdotL = max0(dot3(N, L));
+    const float G = geometry_schlick_ggx(NdotV, m.roughness) * geometry_schlick_ggx(NdotL, m.roughness);
+    const float ct = saturatef(max0(dot3(H, V)));
+    const float p5 = fpow(1.0f - ct, 5.0f);                                             // FresnelSchlick :131-136
+    const f3 F = {F0.x + (1.0f - F0.x) * p5, F0.y + (1.0f - F0.y) * p5, F0.z + (1.0f - F0.z) * p5};
+    const float om = 1.0f - m.metallic;
+    const f3 kD = {(1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om};
+    const float ndg = NDF * G;
+    const float denominator = (4.0f * NdotV) * NdotL + PBR_EPSILON;
+    const f3 specular = {(ndg * F.x) / denominator, (ndg * F.y) / denominator, (ndg * F.z) / denominator};
+    return {(((kD.x * m.albedo.x) / PBR_PI + specular.x) * radiance.x) * NdotL,
+            (((kD.y * m.albedo.y) / PBR_PI + specular.y) * radiance.y) * NdotL,
+            (((kD.z * m.albedo.z) / PBR_PI + specular.z) * radiance.z) * NdotL};
+}
+
+// pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
+__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyings vv[3], f3 worldPos, f3 V, f3 N) {
+    const CBytePtr M = cb(D.material);                                                  // MaterialData :36-59 (80 B)
+    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
+    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+    f4 baseColor = {ldcf(M, 0), ldcf(M, 4), ldcf(M, 8), ldcf(M, 12)};
+    float metallic = ldcf(M, 16), roughness = ldcf(M, 20), ao = ldcf(M, 24);
+    const float normalScale = ldcf(M, 28);
+    f3 emissive = {ldcf(M, 32), ldcf(M, 36), ldcf(M, 40)};
+    if (ldcu(M, 48) != 0u) {
+        const f4 t = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+        baseColor = {t.x * baseColor.x, t.y * baseColor.y, t.z * baseColor.z, t.w * baseColor.w};
+    }
+    if (ldcu(M, 56) != 0u) {
+        const f4 t = sample_bilinear(D.tex[2], D.tex_w[2], D.tex_h[2], u, v);
+        roughness = roughness * t.y; metallic = metallic * t.z;
+    }
+    if (ldcu(M, 60) != 0u) ao = ao * sample_bilinear(D.tex[3], D.tex_w[3], D.tex_h[3], u, v).x;
+    if (ldcu(M, 64) != 0u) {
+        const f4 t = sample_bilinear(D.tex[4], D.tex_w[4], D.tex_h[4], u, v);
+        emissive = {emissive.x * t.x, emissive.y * t.y, emissive.z * t.z};
+    }
+    if (ldcu(M, 52) != 0u) {                                                            // GetWorldNormal :124-151
+        const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+        const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
+        if (!(length3(ncm1) < 0.01f)) {
+            const f3 ns = normalize3({(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f});
+            const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
+            const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+            N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
+        }
+    }
+    PbrMaterial m;
+    m.albedo = {baseColor.x, baseColor.y, baseColor.z};
+    m.metallic = metallic;
+    m.roughness = roughness > 0.04f ? roughness : 0.04f;                                // ClampRoughness :476-479
+    f3 lighting = {0.0f, 0.0f, 0.0f};
+    {
+        const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
+        const float intensity = ldcf(cb(D.lights), 12);
+        const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
+        lighting = add3(lighting, pbr_direct(N, V, normalize3({-dir.x, -dir.y, -dir.z}), scale3(color, intensity), m));
+    }
+    const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
+    const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
+    for (uint32_t i = 0; i < numPoint; i++) {
+        const CBytePtr Lp = cb(D.point_lights) + 32u * i;
+        const f3 pos = {ldcf(Lp, 0), ldcf(Lp, 4), ldcf(Lp, 8)};
+        const float radius = ldcf(Lp, 12);
+        const f3 color = {ldcf(Lp, 16), ldcf(Lp, 20), ldcf(Lp, 24)};
+        const float intensity = ldcf(Lp, 28);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(color, intensity), attenuation(dist, radius)), m));
+    }
+    for (uint32_t j = 0; j < numSpot; j++) {
+        const CBytePtr Ls = cb(D.spot_lights) + 48u * j;
+        const f3 pos = {ldcf(Ls, 0), ldcf(Ls, 4), ldcf(Ls, 8)};
+        const float innerCos = ldcf(Ls, 12);
+        const f3 sdir = {ldcf(Ls, 16), ldcf(Ls, 20), ldcf(Ls, 24)};
+        const float outerCos = ldcf(Ls, 28);
+        const f3 color = {ldcf(Ls, 32), ldcf(Ls, 36), ldcf(Ls, 40)};
+        const float intensity = ldcf(Ls, 44);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        const float datt = attenuation(dist, 50.0f);
+        const f3 sd = normalize3(sdir);
+        const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);
+        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(scale3(color, intensity), datt), satt), m));
+    }
+    const float up = N.y * 0.5f + 0.5f;                                                 // CalculateHemisphereAmbient pbr.hlsli:483-492
+    const f3 amb = {0.08f + (0.15f - 0.08f) * up, 0.06f + (0.18f - 0.06f) * up, 0.04f + (0.25f - 0.04f) * up};
+    const float om = 1.0f - m.metallic;
+    const f3 ambient = scale3(scale3(mul3(amb, m.albedo), ao), om);
+    lighting = scale3(lighting, 1.0f + (ao - 1.0f) * 0.5f);                             // lerp(1, ao, 0.5) :311
+    const f3 col = add3(add3(ambient, lighting), emissive);
+    return {col.x, col.y, col.z, baseColor.w};
+}
+
+template <bool PBR>
+__device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
+    f4 c[3]; Varyings vv[3];
+    const bool full = D.program >= 2;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)fetch_index(D, 3u * tri + k) * D.vs_words;
+        const uint4 w0 = sv[0], w1 = sv[1], w2 = sv[2];
+        c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+        vv[k].world = {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)};
+        vv[k].normal = {__uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y)};
+        if (full) {
+            const uint4 w3 = sv[3], w4 = sv[4];
+            vv[k].u = __uint_as_float(w2.z); vv[k].v = __uint_as_float(w2.w);
+            vv[k].tangent = {__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z)};
+            vv[k].bitangent = {__uint_as_float(w3.w), __uint_as_float(w4.x), __uint_as_float(w4.y)};
+        }
+    }
+    float b[3];
+    barycentrics<false>(D, c, pxc, pyc, b);
+    const f3 worldPos = interp3(b, vv[0].world, vv[1].world, vv[2].world);
+    const f3 Nv = interp3(b, vv[0].normal, vv[1].normal, vv[2].normal);
+    const CFloatPtr cam = cf(D.camera);
+    const f3 camPos = {cam[48], cam[49], cam[50]};          // cameraPosition @192 B
+    const f3 V = normalize3(sub3(camPos, worldPos));
+    f3 N = normalize3(Nv);
+
+    if (!full) {                                                             // pixel/model.hlsl:29-82
+        const f3 albedo = {0.7f, 0.7f, 0.7f};
+        const f3 one = {1.0f, 1.0f, 1.0f};
+        const f3 L = normalize3(one);
+        const f3 ambient = scale3(scale3(albedo, 0.03f), 1.0f);
+        const f3 lighting = blinn_phong(L, V, N, one, albedo, roughness_to_shininess(0.5f));
+        const f3 col = add3(ambient, lighting);
+        return {col.x, col.y, col.z, 1.0f};
+    }
+    if (PBR && D.program == 3) return shade_pbr(D, b, vv, worldPos, V, N);
+    // pixel/model_full.hlsl:85-150
+    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
+    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+    const f4 baseColor = {ldcf(cb(D.material), 0), ldcf(cb(D.material), 4), ldcf(cb(D.material), 8), ldcf(cb(D.material), 12)};
+    const float roughness = ldcf(cb(D.material), 20), ao = ldcf(cb(D.material), 24);
+    const f4 albedoSample = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+    const f3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
+    const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+    const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
+    const bool hasNormalMap = length3(ncm1) > 0.01f;                          // :94-95
+    if (hasNormalMap) {                                                      // GetWorldNormal :63-83
+        const f3 ns = {nc.x * 2.0f - 1.0f, nc.y * 2.0f - 1.0f, nc.z * 2.0f - 1.0f};
+        const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
+        const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+        N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
+    }
+    const f3 ambient = scale3(scale3(albedo, 0.03f), ao);
+    f3 lighting = {0.0f, 0.0f, 0.0f};
+    const float shininess = roughness_to_shininess(roughness);
+    {   // CalculateDirectionalLight lights.hlsli:166-179 (HLSL DirectionalLight layout :17-23)
+        const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
+        const float intensity = ldcf(cb(D.lights), 12);
+        const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
+        const f3 L = normalize3({-dir.x, -dir.y, -dir.z});
+        lighting = add3(lighting, blinn_phong(L, V, N, scale3(color, intensity), albedo, shininess));
+    }
+    const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
+    const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
+    for (uint32_t i = 0; i < numPoint; i++) {                                // CalculatePointLight :182-199
+        const CBytePtr Lp = cb(D.point_lights) + 32u * i;
+        const f3 pos = {ldcf(Lp, 0), ldcf(Lp, 4), ldcf(Lp, 8)};
+        const float radius = ldcf(Lp, 12);
+        const f3 color = {ldcf(Lp, 16), ldcf(Lp, 20), ldcf(Lp, 24)};
+        const float intensity = ldcf(Lp, 28);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        const f3 lc = scale3(scale3(color, intensity), attenuation(dist, radius));
+        lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
+    }
+    for (uint32_t j = 0; j < numSpot; j++) {                                 // CalculateSpotLight :202-231
+        const CBytePtr Ls = cb(D.spot_lights) + 48u * j;
+        const f3 pos = {ldcf(Ls, 0), ldcf(Ls, 4), ldcf(Ls, 8)};
+        const float innerCos = ldcf(Ls, 12);
+        const f3 sdir = {ldcf(Ls, 16), ldcf(Ls, 20), ldcf(Ls, 24)};
+        const float outerCos = ldcf(Ls, 28);
+        const f3 color = {ldcf(Ls, 32), ldcf(Ls, 36), ldcf(Ls, 40)};
+        const float intensity = ldcf(Ls, 44);
+        const f3 lv = sub3(pos, worldPos);
+        const float dist = length3(lv);
+        const f3 L = scale3(lv, 1.0f / dist);
+        const float datt = attenuation(dist, 50.0f);
+        const f3 sd = normalize3(sdir);
+        const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);                // CalculateSpotAttenuation :77-81
+        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        const f3 lc = scale3(scale3(scale3(color, intensity), datt), satt);
+        lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
+    }
+    const f3 col = add3(ambient, lighting);
+    return {col.x, col.y, col.z, albedoSample.w * baseColor.w};
+}
+
+#pragma clang fp contract(fast)
+// a9: sRGB OETF + UNORM8, BGRA byte order (swapchain.rs:561-570)
+__device__ __forceinline__ uint32_t srgb8(float c) {
+    c = saturatef(c);
+    float e = (c <= 0.0031308f) ? 12.92f * c : 1.055f * __builtin_amdgcn_exp2f((1.0f / 2.4f) * __builtin_amdgcn_logf(c)) - 0.055f;
+    e = saturatef(e);
+    return (uint32_t)rintf(e * 255.0f);
+}
+__device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c) {
+    return srgb8(c.z) | (srgb8(c.y) << 8) | (srgb8(c.x) << 16) | ((uint32_t)rintf(saturatef(c.w) * 255.0f) << 24);
+}
+
+#endif  // MIRHI_SHADING_HIP_H
