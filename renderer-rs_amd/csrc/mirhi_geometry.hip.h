@@ -235,6 +235,32 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
     }
     const bool binned = valid && !spill;
     const uint32_t nb = binned ? (uint32_t)(ntx * nty) : 0u;
+    if (__ballot(nb > 1u) == 0ull) {
+        // Fine meshes: no triangle of the wave overlaps more than one tile.  A lane is its own pair -- no enumeration
+        // through LDS, the record goes out of the registers it was built in.
+        constexpr int GROUP_ROUNDS = 8, GROUP_MIN = 2;
+        const uint32_t tile = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+        const bool act = nb == 1u;
+        uint32_t raw = 0, who = lane;
+        uint64_t rem = __ballot(act);
+        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+            const uint64_t grp = __ballot(act && tile == t0) & rem;
+            if (__popcll(grp) < GROUP_MIN) break;
+            if (act && tile == t0 && ((rem >> lane) & 1ull)) who = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
+            if ((int)lane == leader) raw = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
+            rem &= ~grp;
+        }
+        if (act && ((rem >> lane) & 1ull)) raw = atomicAdd(&P.bin_count[tile], 1u);      // ungrouped lanes
+        const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
+        if (act) {
+            if (slot < P.bin_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
+            else spill = true;       // bin full: the triangle goes to the big list
+        }
+        if (valid && spill) emit_big(P, t);
+        return;
+    }
     // exclusive prefix sum of nb (<= 16) over the wave from five bit planes of ballots
     uint32_t ex = 0, total = 0;
 #pragma unroll
