@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "mirhi.hpp"
+#include "gltf.hpp"
 
 using namespace mirhi;
 
@@ -72,6 +73,23 @@ static void cpu_tests() {
     Mesh mesh; mesh.positions = {{0, 0, 0}, {1, 0, 0}};
     auto vs = mesh.interleave();
     CHECK(vs.size() == 2 && vs[1].normal.y == 1.0f && vs[0].tangent.x == 1.0f && vs[0].tangent.w == 1.0f && vs[1].tex_coord.x == 0.0f);
+    // Model::load (model.rs:111-270) on the dancer fixture: K5 counts and the loader's defaults
+    if (const char* gltf = std::getenv("MIRHI_TEST_GLTF")) {
+        const resources::Model m = resources::Model::load(gltf);
+        CHECK(m.meshes.size() == 1 && m.total_vertices() == 11865 && m.total_triangles() == 17210);
+        CHECK(m.materials.size() == 1 && m.meshes[0].material_index.has_value() && *m.meshes[0].material_index == 0);
+        CHECK(near(m.aabb_min.x, -0.95f) && near(m.aabb_max.y, 0.769373f) && near(m.aabb_min.z, -0.92852f));
+        for (auto& me : m.meshes) CHECK(me.positions.size() == me.normals.size() && me.positions.size() == me.tex_coords.size() && me.positions.size() == me.tangents.size());
+        CHECK(m.aabb_min.x < m.aabb_max.x && m.aabb_min.y < m.aabb_max.y && m.aabb_min.z < m.aabb_max.z);
+        uint32_t max_index = 0;
+        for (uint32_t i : m.meshes[0].indices) max_index = i > max_index ? i : max_index;
+        CHECK(max_index + 1 == m.meshes[0].positions.size());
+        const auto vs0 = m.meshes[0].interleave();
+        CHECK(vs0.size() == m.meshes[0].positions.size() && sizeof(vs0[0]) == 48);
+        bool threw = false;
+        try { resources::Model::load("/nonexistent/file.gltf"); } catch (const resources::ResourceError& e) { threw = std::strstr(e.what(), "File not found") != nullptr; }
+        CHECK(threw);
+    }
     // no GPU -> NoSuitableGpu, never a fallback
     int32_t n = 0; mirhi_device_count(&n);
     if (n == 0) {

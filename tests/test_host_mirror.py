@@ -17,7 +17,8 @@ def _build(mirhi):
 
 def test_host_mirror_cpu(mirhi):
     exe = _build(mirhi)
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, MIRHI_TEST_GLTF=os.path.join(ROOT, "tests", "golden", "dancer", "scene.gltf"))   # Model::load, K5 counts
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0 and "host tests: ok" in out.stdout, out.stdout + out.stderr
 
 
