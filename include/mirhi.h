@@ -103,12 +103,19 @@ typedef enum {
     MIRHI_FORMAT_R32G32B32A32_SFLOAT = 2,
     MIRHI_FORMAT_D32_SFLOAT = 3,
     MIRHI_FORMAT_R8G8B8A8_UNORM = 4,
-    MIRHI_FORMAT_R32_UINT = 5       /* debug/parity: winning primitive id per pixel */
+    MIRHI_FORMAT_R32_UINT = 5,      /* debug/parity: winning primitive id per pixel */
+    MIRHI_FORMAT_R8G8B8A8_SRGB = 6  /* sampled colour textures: RGB decoded to linear on sampling */
 } mirhi_format;
 mirhi_result mirhi_image_create(mirhi_device* dev, uint32_t width, uint32_t height, mirhi_format format, mirhi_image** out); /* DepthBuffer::new depth_buffer.rs:117-127 (0 size -> error) */
 mirhi_result mirhi_image_wrap_device_memory(mirhi_device* dev, uint32_t width, uint32_t height, mirhi_format format, void* device_ptr, mirhi_image** out);
 mirhi_result mirhi_image_upload(mirhi_image* img, const void* src, uint64_t len);
 mirhi_result mirhi_image_read(mirhi_image* img, void* dst, uint64_t len);   /* added: swapchain images have no readback (swapchain.rs:255) */
+/* Texture fidelity (image.rs / sampler.rs / texture.rs are stubs in the reference, the shaders assume
+ * `SamplerState` filtering, model_full.hlsl:44-46): builds the full mip chain of an owned R8G8B8A8 image from its level 0
+ * (2x2 box filter on the stored bytes, round half up, edge clamp for odd sizes).  A texture with a chain is sampled
+ * trilinearly (LOD from the analytic screen-space UV derivatives), one without bilinearly.  Call again after an upload. */
+mirhi_result mirhi_image_generate_mips(mirhi_image* img);
+uint32_t     mirhi_image_mip_levels(const mirhi_image* img);
 uint32_t     mirhi_image_width(const mirhi_image* img);
 uint32_t     mirhi_image_height(const mirhi_image* img);
 int32_t      mirhi_image_format(const mirhi_image* img);

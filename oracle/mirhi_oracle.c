@@ -115,30 +115,67 @@ uint8_t oracle_srgb8(float c) {
 static uint8_t unorm8(float a) { return (uint8_t)rintf(saturatef(a) * 255.0f); }
 
 /* ------------------------------------------------------------------------------------------------
- * texture sampling: bilinear, repeat, no mips (model_full.hlsl:44-46 declares one linear sampler;
+ * texture sampling: bilinear or trilinear, repeat (model_full.hlsl:44-46 declares one linear sampler;
  * crates/rhi/src/{image,sampler,texture}.rs are empty stubs, so addressing/filtering is this
  * build's stated choice: VK_SAMPLER_ADDRESS_MODE_REPEAT, VK_FILTER_LINEAR, UNORM texels)
  * ---------------------------------------------------------------------------------------------- */
-static v4 texel(const oracle_texture* t, int32_t x, int32_t y) {
-    int32_t w = (int32_t)t->width, h = (int32_t)t->height;
+static float srgb_to_linear(uint8_t byte) {                     /* sRGB EOTF per byte: double, rounded once (as mirhi_api.hip) */
+    static float lut[256];
+    static int ready = 0;
+    if (!ready) {
+        for (int i = 0; i < 256; i++) {
+            double c = (double)i / 255.0;
+            lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+        }
+        ready = 1;      /* benign race between band threads: every writer stores the same values */
+    }
+    return lut[byte];
+}
+static v4 texel(const uint8_t* level, int32_t w, int32_t h, int32_t x, int32_t y, int srgb) {
     x %= w; if (x < 0) x += w;
     y %= h; if (y < 0) y += h;
-    const uint8_t* p = t->rgba8 + 4u * ((uint32_t)y * t->width + (uint32_t)x);
+    const uint8_t* p = level + 4u * ((uint32_t)y * (uint32_t)w + (uint32_t)x);
     v4 r = {(float)p[0] * (1.0f / 255.0f), (float)p[1] * (1.0f / 255.0f), (float)p[2] * (1.0f / 255.0f),
             (float)p[3] * (1.0f / 255.0f)};
+    if (srgb) { r.x = srgb_to_linear(p[0]); r.y = srgb_to_linear(p[1]); r.z = srgb_to_linear(p[2]); }
     return r;
 }
-static v4 sample_bilinear(const oracle_texture* t, float u, float v) {
-    if (!t->rgba8 || t->width == 0 || t->height == 0) { v4 one = {1.0f, 1.0f, 1.0f, 1.0f}; return one; }
-    float fx = u * (float)t->width - 0.5f, fy = v * (float)t->height - 0.5f;
+/* bilinear tap of one mip level, repeat addressing */
+static v4 sample_level(const uint8_t* level, uint32_t w, uint32_t h, float u, float v, int srgb) {
+    float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
     float x0f = floorf(fx), y0f = floorf(fy);
     float ax = fx - x0f, ay = fy - y0f;
     int32_t x0 = (int32_t)x0f, y0 = (int32_t)y0f;
-    v4 c00 = texel(t, x0, y0), c10 = texel(t, x0 + 1, y0), c01 = texel(t, x0, y0 + 1), c11 = texel(t, x0 + 1, y0 + 1);
+    v4 c00 = texel(level, (int32_t)w, (int32_t)h, x0, y0, srgb), c10 = texel(level, (int32_t)w, (int32_t)h, x0 + 1, y0, srgb);
+    v4 c01 = texel(level, (int32_t)w, (int32_t)h, x0, y0 + 1, srgb), c11 = texel(level, (int32_t)w, (int32_t)h, x0 + 1, y0 + 1, srgb);
     v4 r;
 #define LERP2(f) r.f = (c00.f + (c10.f - c00.f) * ax) + ((c01.f + (c11.f - c01.f) * ax) - (c00.f + (c10.f - c00.f) * ax)) * ay
     LERP2(x); LERP2(y); LERP2(z); LERP2(w);
 #undef LERP2
+    return r;
+}
+/* screen-space derivatives of (u, v): the value one pixel to the right / one pixel down minus the value at the pixel */
+typedef struct { float dudx, dvdx, dudy, dvdy; } uv_grad;
+/* Without a chain: bilinear.  With one: trilinear, lambda = 0.5 * log2(max(|d(uv*size)/dx|^2, |d(uv*size)/dy|^2)) clamped to
+ * [0, levels - 1] (Vulkan 1.3 15.6.7 with the exact footprint axes instead of an approximation) */
+static v4 sample_texture(const oracle_texture* t, float u, float v, const uv_grad* g) {
+    if (!t->rgba8 || t->width == 0 || t->height == 0) { v4 one = {1.0f, 1.0f, 1.0f, 1.0f}; return one; }
+    const uint32_t levels = t->levels ? t->levels : 1u;
+    if (levels <= 1u) return sample_level(t->rgba8, t->width, t->height, u, v, (int)t->srgb);
+    float ax = g->dudx * (float)t->width, bx = g->dvdx * (float)t->height, ay = g->dudy * (float)t->width, by = g->dvdy * (float)t->height;
+    float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+    float lam = 0.5f * log2f(rx > ry ? rx : ry);
+    if (!(lam > 0.0f)) lam = 0.0f;
+    float top = (float)(levels - 1u);
+    if (lam > top) lam = top;
+    float l0f = floorf(lam), f = lam - l0f;
+    uint32_t l0 = (uint32_t)l0f, lw = t->width, lh = t->height;
+    const uint8_t* level = t->rgba8;
+    for (uint32_t l = 0; l < l0; l++) { level += 4u * (size_t)lw * lh; lw = lw > 1u ? lw >> 1 : 1u; lh = lh > 1u ? lh >> 1 : 1u; }
+    v4 c0 = sample_level(level, lw, lh, u, v, (int)t->srgb);
+    if (l0 + 1u >= levels) return c0;
+    v4 c1 = sample_level(level + 4u * (size_t)lw * lh, lw > 1u ? lw >> 1 : 1u, lh > 1u ? lh >> 1 : 1u, u, v, (int)t->srgb);
+    v4 r = {c0.x + (c1.x - c0.x) * f, c0.y + (c1.y - c0.y) * f, c0.z + (c1.z - c0.z) * f, c0.w + (c1.w - c0.w) * f};
     return r;
 }
 
@@ -359,7 +396,7 @@ static int depth_cmp(uint32_t op, float z, float stored) {
  * a8: fragment shading of one visible pixel
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { v3 world, normal, tangent, bitangent; float u, v; v3 color; } varyings;
-static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, float rgba[4]);
+static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, const void* gradp, float rgba[4]);
 
 static void vs_varyings(const oracle_draw* d, uint32_t vidx, v4* clip, varyings* o) {
     const uint8_t* vtx = d->vertex_data + (size_t)vidx * d->vertex_stride;
@@ -436,15 +473,38 @@ static void shade_pixel(const oracle_pass* pass, const oracle_draw* d, uint32_t 
         rgba[0] = col.x; rgba[1] = col.y; rgba[2] = col.z; rgba[3] = 1.0f;
         return;
     }
-    if (d->program == ORACLE_PROGRAM_MODEL_PBR) { shade_pbr(d, b, vv, worldPos, Nv, V, rgba); return; }
+    /* mip-mapped textures: footprint of (u, v) from the same interpolation one pixel right / down (exact for a planar triangle) */
+    uv_grad grad = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const oracle_texture* tx[5] = {&d->albedo_map, &d->normal_map, &d->metallic_roughness_map, &d->occlusion_map, &d->emissive_map};
+        int any = 0;
+        for (int k = 0; k < (d->program == ORACLE_PROGRAM_MODEL_PBR ? 5 : 2); k++) any |= tx[k]->rgba8 && tx[k]->levels > 1u;
+        if (any) {
+            float u0 = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u, v0 = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+            for (int axis = 0; axis < 2; axis++) {
+                const float qx = axis == 0 ? pxc + 1.0f : pxc, qy = axis == 0 ? pyc : pyc + 1.0f;
+                float gx[3], gy[3];
+                for (int k = 0; k < 3; k++) {
+                    gx[k] = (c[k].x * hw + c[k].w * cx) - qx * c[k].w;
+                    gy[k] = (c[k].y * hh + c[k].w * cy) - qy * c[k].w;
+                }
+                float m0 = gx[1] * gy[2] - gx[2] * gy[1], m1 = gx[2] * gy[0] - gx[0] * gy[2], m2 = gx[0] * gy[1] - gx[1] * gy[0];
+                float minv = 1.0f / ((m0 + m1) + m2);
+                float bb[3] = {m0 * minv, m1 * minv, m2 * minv};
+                float uu = (bb[0] * vv[0].u + bb[1] * vv[1].u) + bb[2] * vv[2].u, vq = (bb[0] * vv[0].v + bb[1] * vv[1].v) + bb[2] * vv[2].v;
+                if (axis == 0) { grad.dudx = uu - u0; grad.dvdx = vq - v0; } else { grad.dudy = uu - u0; grad.dvdy = vq - v0; }
+            }
+        }
+    }
+    if (d->program == ORACLE_PROGRAM_MODEL_PBR) { shade_pbr(d, b, vv, worldPos, Nv, V, &grad, rgba); return; }
     /* ORACLE_PROGRAM_MODEL_FULL: pixel/model_full.hlsl:85-150 */
     float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
     v4 baseColor = {rdf(d->material, 0), rdf(d->material, 4), rdf(d->material, 8), rdf(d->material, 12)};
     float roughness = rdf(d->material, 20), ao = rdf(d->material, 24);
-    v4 albedoSample = sample_bilinear(&d->albedo_map, u, v);
+    v4 albedoSample = sample_texture(&d->albedo_map, u, v, &grad);
     v3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
-    v4 nc = sample_bilinear(&d->normal_map, u, v);
+    v4 nc = sample_texture(&d->normal_map, u, v, &grad);
     v3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
     int hasNormalMap = length3(ncm1) > 0.01f;                    /* model_full.hlsl:94-95 */
     v3 N = normalize3(Nv);
@@ -547,7 +607,8 @@ static v3 pbr_direct(v3 N, v3 V, v3 L, v3 radiance, const pbr_material* m) {   /
  * raster + resolve + shade of one row band
  * ---------------------------------------------------------------------------------------------- */
 
-static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, float rgba[4]) {
+static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v3 worldPos, v3 Nv, v3 V, const void* gradp, float rgba[4]) {
+    const uv_grad grad = *(const uv_grad*)gradp;
     /* pixel/model_pbr.hlsl:159-320; MaterialData :36-59 (80 B) */
     const varyings* vv = (const varyings*)vvp;
     const void* M = d->material;
@@ -558,15 +619,15 @@ static void shade_pbr(const oracle_draw* d, const float b[3], const void* vvp, v
     v3 emissive = {rdf(M, 32), rdf(M, 36), rdf(M, 40)};
     uint32_t hasBase = rdu(M, 48), hasNormal = rdu(M, 52), hasMR = rdu(M, 56), hasOcc = rdu(M, 60), hasEm = rdu(M, 64);
     if (hasBase) {
-        v4 t = sample_bilinear(&d->albedo_map, u, v);
+        v4 t = sample_texture(&d->albedo_map, u, v, &grad);
         baseColor.x = t.x * baseColor.x; baseColor.y = t.y * baseColor.y; baseColor.z = t.z * baseColor.z; baseColor.w = t.w * baseColor.w;
     }
-    if (hasMR) { v4 t = sample_bilinear(&d->metallic_roughness_map, u, v); roughness = roughness * t.y; metallic = metallic * t.z; }
-    if (hasOcc) { v4 t = sample_bilinear(&d->occlusion_map, u, v); ao = ao * t.x; }
-    if (hasEm) { v4 t = sample_bilinear(&d->emissive_map, u, v); emissive.x *= t.x; emissive.y *= t.y; emissive.z *= t.z; }
+    if (hasMR) { v4 t = sample_texture(&d->metallic_roughness_map, u, v, &grad); roughness = roughness * t.y; metallic = metallic * t.z; }
+    if (hasOcc) { v4 t = sample_texture(&d->occlusion_map, u, v, &grad); ao = ao * t.x; }
+    if (hasEm) { v4 t = sample_texture(&d->emissive_map, u, v, &grad); emissive.x *= t.x; emissive.y *= t.y; emissive.z *= t.z; }
     v3 N = normalize3(Nv);                                                  /* GetWorldNormal :124-151 */
     if (hasNormal) {
-        v4 nc = sample_bilinear(&d->normal_map, u, v);
+        v4 nc = sample_texture(&d->normal_map, u, v, &grad);
         v3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
         if (!(length3(ncm1) < 0.01f)) {
             v3 ns = {(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f};

@@ -41,8 +41,12 @@ enum { ORACLE_CMP_NEVER = 0, ORACLE_CMP_LESS = 1, ORACLE_CMP_EQUAL = 2, ORACLE_C
        ORACLE_CMP_GREATER = 4, ORACLE_CMP_NOT_EQUAL = 5, ORACLE_CMP_GREATER_OR_EQUAL = 6, ORACLE_CMP_ALWAYS = 7 };
 
 typedef struct {
-    const uint8_t* rgba8; /* row-major, 4 bytes per texel, UNORM */
+    const uint8_t* rgba8; /* row-major, 4 bytes per texel; level 0 first, then levels 1..levels-1 back to back */
     uint32_t width, height;
+    /* SURVEY 8f rank 3 (texture fidelity): levels > 1 = a mip chain follows level 0 (each level max(1, w>>1) x max(1, h>>1))
+     * and the texture is sampled trilinearly; srgb = the RGB bytes are sRGB-encoded and decoded to linear when sampled.
+     * 0 levels means 1. */
+    uint32_t levels, srgb;
 } oracle_texture;
 
 typedef struct {

@@ -33,7 +33,7 @@ class BufferUsage:  # crates/rhi/src/buffer.rs:47-60
 
 
 class Format:
-    UNDEFINED, B8G8R8A8_SRGB, R32G32B32A32_SFLOAT, D32_SFLOAT, R8G8B8A8_UNORM, R32_UINT = range(6)
+    UNDEFINED, B8G8R8A8_SRGB, R32G32B32A32_SFLOAT, D32_SFLOAT, R8G8B8A8_UNORM, R32_UINT, R8G8B8A8_SRGB = range(7)
 
 
 class Program:
@@ -163,6 +163,8 @@ _SIGNATURES = {
     "mirhi_image_wrap_device_memory": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirhi_image_upload": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "mirhi_image_read": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "mirhi_image_generate_mips": (C.c_int32, [C.c_void_p]),
+    "mirhi_image_mip_levels": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_width": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_height": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_format": (C.c_int32, [C.c_void_p]),
@@ -362,6 +364,14 @@ class Image:
     def upload(self, data):
         arr = _as_bytes(data)
         check(lib().mirhi_image_upload(self.handle, arr.ctypes.data, arr.size))
+
+    def generate_mips(self):
+        """Full mip chain from level 0 (include/mirhi.h); the image is sampled trilinearly from then on."""
+        check(lib().mirhi_image_generate_mips(self.handle))
+
+    @property
+    def mip_levels(self) -> int:
+        return int(lib().mirhi_image_mip_levels(self.handle))
 
     def read(self) -> np.ndarray:
         n = lib().mirhi_image_size_bytes(self.handle)
@@ -606,8 +616,10 @@ class SceneResources:
                 return None
             if id(t) in cache:
                 return cache[id(t)]
-            img = Image(device, t.width, t.height, Format.R8G8B8A8_UNORM)
+            img = Image(device, t.width, t.height, Format.R8G8B8A8_SRGB if t.srgb else Format.R8G8B8A8_UNORM)
             img.upload(np.ascontiguousarray(t.rgba8))
+            if t.mips:
+                img.generate_mips()
             cache[id(t)] = img
             self.objs.append(img)
             return img

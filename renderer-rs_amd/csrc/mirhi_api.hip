@@ -112,6 +112,7 @@ struct mirhi_image {
     mirhi_format format;
     uint8_t* ptr;
     bool owned;
+    uint32_t levels = 1;      // mip levels stored contiguously behind level 0 (mirhi_image_generate_mips)
 };
 
 struct mirhi_pipeline {
@@ -187,7 +188,7 @@ struct mirhi_fence {
 static uint32_t format_bpp(mirhi_format f) {
     switch (f) {
         case MIRHI_FORMAT_B8G8R8A8_SRGB: case MIRHI_FORMAT_D32_SFLOAT: case MIRHI_FORMAT_R8G8B8A8_UNORM:
-        case MIRHI_FORMAT_R32_UINT: return 4;
+        case MIRHI_FORMAT_R8G8B8A8_SRGB: case MIRHI_FORMAT_R32_UINT: return 4;
         case MIRHI_FORMAT_R32G32B32A32_SFLOAT: return 16;
         default: return 0;
     }
@@ -228,6 +229,15 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
         d->owns_stream = true;
     }
     d->lanes.push_back(d->stream);
+    {   // sRGB EOTF per byte, evaluated in double and rounded once (the oracle builds the identical table)
+        float lut[256];
+        for (int i = 0; i < 256; i++) {
+            const double c = (double)i / 255.0;
+            lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+        }
+        const hipError_t le = upload_srgb_lut(lut);
+        if (le != hipSuccess) { if (d->owns_stream) (void)hipStreamDestroy(d->stream); delete d; return hip_fail(le, "sRGB table upload"); }
+    }
     *out = d;
     return MIRHI_OK;
 }
@@ -442,6 +452,51 @@ extern "C" mirhi_result mirhi_image_read(mirhi_image* img, void* dst, uint64_t l
     { mirhi_result r0 = sync_all_lanes(img->dev); if (r0 != MIRHI_OK) return r0; }
     HIP_TRY(hipMemcpyAsync(dst, img->ptr, len, hipMemcpyDeviceToHost, img->dev->stream));
     HIP_TRY(hipStreamSynchronize(img->dev->stream));
+    return MIRHI_OK;
+}
+// one thread per texel of the destination level: 2x2 box filter on the stored bytes, round half up, edge clamp
+__global__ void mip_kernel(const uint32_t* __restrict__ src, uint32_t sw, uint32_t sh, uint32_t* __restrict__ dst, uint32_t dw, uint32_t dh) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint32_t x0 = 2u * x < sw ? 2u * x : sw - 1u, x1 = 2u * x + 1u < sw ? 2u * x + 1u : sw - 1u;
+    const uint32_t y0 = 2u * y < sh ? 2u * y : sh - 1u, y1 = 2u * y + 1u < sh ? 2u * y + 1u : sh - 1u;
+    const uint32_t a = src[y0 * sw + x0], b = src[y0 * sw + x1], c = src[y1 * sw + x0], e = src[y1 * sw + x1];
+    uint32_t out = 0;
+    for (uint32_t sft = 0; sft < 32u; sft += 8u)
+        out |= ((((a >> sft) & 0xFFu) + ((b >> sft) & 0xFFu) + ((c >> sft) & 0xFFu) + ((e >> sft) & 0xFFu) + 2u) >> 2) << sft;
+    dst[y * dw + x] = out;
+}
+extern "C" uint32_t mirhi_image_mip_levels(const mirhi_image* img) { return img ? img->levels : 0; }
+extern "C" mirhi_result mirhi_image_generate_mips(mirhi_image* img) {
+    NULL_CHECK(img, "image");
+    if (img->format != MIRHI_FORMAT_R8G8B8A8_UNORM && img->format != MIRHI_FORMAT_R8G8B8A8_SRGB)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: mip chains are built for R8G8B8A8 textures only");
+    if (!img->owned) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: cannot grow a wrapped image into a mip chain");
+    HIP_TRY(hipSetDevice(img->dev->ordinal));
+    { mirhi_result r0 = sync_all_lanes(img->dev); if (r0 != MIRHI_OK) return r0; }
+    uint32_t levels = 1;
+    size_t texels = (size_t)img->width * img->height;
+    for (uint32_t w = img->width, h = img->height; w > 1 || h > 1; levels++) { w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; texels += (size_t)w * h; }
+    uint8_t* chain = img->ptr;
+    if (img->levels != levels) {              // first call: move level 0 into a buffer that holds the whole chain
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, texels * 4);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc for a %zu-texel mip chain: %s", texels, hipGetErrorString(e)); }
+        chain = (uint8_t*)p;
+        HIP_TRY(hipMemcpyAsync(chain, img->ptr, (size_t)img->width * img->height * 4, hipMemcpyDeviceToDevice, img->dev->stream));
+    }
+    uint32_t sw = img->width, sh = img->height;
+    uint32_t* src = (uint32_t*)chain;
+    for (uint32_t l = 1; l < levels; l++) {
+        const uint32_t dw = sw > 1 ? sw >> 1 : 1, dh = sh > 1 ? sh >> 1 : 1;
+        uint32_t* dst = src + (size_t)sw * sh;
+        hipLaunchKernelGGL(mip_kernel, dim3((dw + 63) / 64, dh), dim3(64), 0, img->dev->stream, src, sw, sh, dst, dw, dh);
+        HIP_TRY(hipGetLastError());
+        src = dst; sw = dw; sh = dh;
+    }
+    HIP_TRY(hipStreamSynchronize(img->dev->stream));
+    if (chain != img->ptr) { (void)hipFree(img->ptr); img->ptr = chain; }
+    img->levels = levels;
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_image_destroy(mirhi_image* img) {
@@ -673,7 +728,8 @@ extern "C" mirhi_result mirhi_cmd_bind_uniform(mirhi_cmd* cmd, mirhi_uniform_slo
 extern "C" mirhi_result mirhi_cmd_bind_texture(mirhi_cmd* cmd, mirhi_texture_slot slot, mirhi_image* image) {
     REQUIRE_RECORDING(cmd);
     if ((int)slot < 0 || (int)slot >= MIRHI_TEXTURE_COUNT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown texture slot %d", (int)slot);
-    if (image && image->format != MIRHI_FORMAT_R8G8B8A8_UNORM) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: sampled images must be R8G8B8A8_UNORM");
+    if (image && image->format != MIRHI_FORMAT_R8G8B8A8_UNORM && image->format != MIRHI_FORMAT_R8G8B8A8_SRGB)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: sampled images must be R8G8B8A8_UNORM or R8G8B8A8_SRGB");
     cmd->textures[slot] = image;
     return MIRHI_OK;
 }
@@ -778,7 +834,12 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
             if (cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf) d.point_lights = cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_POINT_LIGHTS].offset;
             if (cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf) d.spot_lights = cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].buf->ptr + cmd->uniforms[MIRHI_SLOT_SPOT_LIGHTS].offset;
             for (int t = 0; t < (d.program == MIRHI_PROGRAM_MODEL_PBR ? 5 : 2); t++)
-                if (cmd->textures[t]) { d.tex[t] = cmd->textures[t]->ptr; d.tex_w[t] = cmd->textures[t]->width; d.tex_h[t] = cmd->textures[t]->height; }
+                if (cmd->textures[t]) {
+                    const mirhi_image* ti = cmd->textures[t];
+                    d.tex[t] = ti->ptr; d.tex_w[t] = ti->width; d.tex_h[t] = ti->height; d.tex_levels[t] = ti->levels;
+                    if (ti->format == MIRHI_FORMAT_R8G8B8A8_SRGB) d.tex_srgb |= 1u << t;
+                    if (ti->levels > 1) d.tex_any_mips = 1;
+                }
         }
     }
     // viewport (Vulkan: xf = (w/2) xd + (x + w/2)), guard-band factors, scissor
@@ -1029,7 +1090,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         all.insert(all.end(), pass.draws.begin(), pass.draws.end());
         cmd->plan.push_back(P);
         uint32_t progs = 0;
-        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : (dd.program == MIRHI_PROGRAM_MODEL_PBR ? 4u : 2u);
+        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : ((dd.program == MIRHI_PROGRAM_MODEL_PBR || dd.tex_any_mips || dd.tex_srgb) ? 4u : 2u);
         cmd->plan_programs.push_back(progs ? progs : 1u);
         cmd->plan_tris += pass.total_tris - pass.first_tri;
     }

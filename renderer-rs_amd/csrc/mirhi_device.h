@@ -37,6 +37,9 @@ struct DrawDesc {
     const uint8_t* spot_lights;   // t1 space1
     const uint8_t* tex[5];        // t0 albedo, t1 normal, t2 metallic-roughness, t3 occlusion, t4 emissive (RGBA8)
     uint32_t tex_w[5], tex_h[5];
+    uint32_t tex_levels[5];       // mip levels stored behind level 0 (1 = no chain: bilinear)
+    uint32_t tex_srgb;            // bit t: texture t is R8G8B8A8_SRGB (RGB decoded to linear when sampled)
+    uint32_t tex_any_mips;        // some bound texture has a chain: the fragment program evaluates UV derivatives
     uint32_t stride;
     uint32_t index_type;          // 0 none, 2 u16, 4 u32
     uint32_t first;               // first_vertex / first_index
@@ -52,7 +55,7 @@ struct DrawDesc {
     int32_t  sx0, sy0, sx1, sy1;  // inclusive scissor (already clamped to render area and extent)
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
     uint32_t vs_words;            // 16-byte words per shaded vertex (3 MODEL, 5 MODEL_FULL, 0 = no vertex pre-pass)
-    uint32_t pad[2];
+    uint32_t pad[3];
     const void* vs_out;           // shaded vertices of this draw's vertex buffer (see VsJob), indexed like the vertex buffer
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");

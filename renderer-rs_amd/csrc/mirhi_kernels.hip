@@ -34,6 +34,10 @@ namespace mirhi {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
+hipError_t upload_srgb_lut(const float* lut) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_lut), lut, 256 * sizeof(float), 0, hipMemcpyHostToDevice);
+}
+
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream) {
     if (P.vs_total_slots == 0) return hipSuccess;
     hipLaunchKernelGGL(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), 0, stream, dev_params);

@@ -316,7 +316,8 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 }
 
 // PROGS: bit 0 = pass contains TRIANGLE-program draws, bit 1 = MODEL / MODEL_FULL draws; 4 = any mix that
-// includes MODEL_PBR draws (its own variant so that the Cook-Torrance code costs the other variants no registers)
+// includes MODEL_PBR draws or mip-mapped textures (its own variant so that the Cook-Torrance and trilinear code costs the
+// other variants no registers)
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
 template <int PROGS, int KEYED, int TP>

@@ -46,8 +46,12 @@ __device__ __forceinline__ f3 blinn_phong(f3 L, f3 V, f3 N, f3 lightColor, f3 al
     return add3(diffuse, scale3(lightColor, sp));
 }
 
-__device__ __forceinline__ f4 unpack_rgba8(uint32_t p) {
+// sRGB byte -> linear, uploaded once per device (mirhi_api.hip builds it in double; the oracle builds the same table)
+__device__ float g_srgb_lut[256];
+
+__device__ __forceinline__ f4 unpack_rgba8(uint32_t p, bool srgb) {
     const float s = 1.0f / 255.0f;
+    if (srgb) return {g_srgb_lut[p & 0xFF], g_srgb_lut[(p >> 8) & 0xFF], g_srgb_lut[(p >> 16) & 0xFF], (float)(p >> 24) * s};
     return {(float)(p & 0xFF) * s, (float)((p >> 8) & 0xFF) * s, (float)((p >> 16) & 0xFF) * s, (float)(p >> 24) * s};
 }
 // repeat addressing of one coordinate: c mod n into [0, n); a mask when n is a power of two (the usual case),
@@ -57,24 +61,51 @@ __device__ __forceinline__ int32_t wrap_coord(int32_t c, int32_t n) {
     c %= n;
     return c < 0 ? c + n : c;
 }
-// bilinear, repeat, no mips (see oracle sample_bilinear)
-__device__ __forceinline__ f4 sample_bilinear(const uint8_t* tex, uint32_t w, uint32_t h, float u, float v) {
-    if (!tex || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
-    const uint32_t* texels = reinterpret_cast<const uint32_t*>(tex);
-    if (w == 1 && h == 1) return unpack_rgba8(texels[0]);
+// bilinear tap of one mip level, repeat addressing (see oracle sample_level)
+__device__ __forceinline__ f4 sample_level(const uint32_t* texels, uint32_t w, uint32_t h, float u, float v, bool srgb) {
+    if (w == 1 && h == 1) return unpack_rgba8(texels[0], srgb);
     const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float ax = fx - x0f, ay = fy - y0f;
     const int32_t x0 = wrap_coord((int32_t)x0f, (int32_t)w), y0 = wrap_coord((int32_t)y0f, (int32_t)h);
     const int32_t x1 = x0 + 1 == (int32_t)w ? 0 : x0 + 1, y1 = y0 + 1 == (int32_t)h ? 0 : y0 + 1;
     const uint32_t r0 = (uint32_t)y0 * w, r1 = (uint32_t)y1 * w;
-    const f4 c00 = unpack_rgba8(texels[r0 + (uint32_t)x0]), c10 = unpack_rgba8(texels[r0 + (uint32_t)x1]);
-    const f4 c01 = unpack_rgba8(texels[r1 + (uint32_t)x0]), c11 = unpack_rgba8(texels[r1 + (uint32_t)x1]);
+    const f4 c00 = unpack_rgba8(texels[r0 + (uint32_t)x0], srgb), c10 = unpack_rgba8(texels[r0 + (uint32_t)x1], srgb);
+    const f4 c01 = unpack_rgba8(texels[r1 + (uint32_t)x0], srgb), c11 = unpack_rgba8(texels[r1 + (uint32_t)x1], srgb);
     f4 r;
 #define MIRHI_LERP2(f) { const float top = c00.f + (c10.f - c00.f) * ax; const float bot = c01.f + (c11.f - c01.f) * ax; r.f = top + (bot - top) * ay; }
     MIRHI_LERP2(x) MIRHI_LERP2(y) MIRHI_LERP2(z) MIRHI_LERP2(w)
 #undef MIRHI_LERP2
     return r;
+}
+// screen-space derivatives of the texture coordinates: (u, v) one pixel to the right and one pixel down, minus (u, v)
+struct UvGrad { float dudx, dvdx, dudy, dvdy; };
+// Texture slot `slot` of the draw at (u, v).  Without a mip chain: bilinear (the reference never creates a sampler --
+// sampler.rs is a stub -- so VK_FILTER_LINEAR / REPEAT is this build's stated choice).  With a chain
+// (mirhi_image_generate_mips): trilinear, LOD = log2 of the longer screen-space footprint axis in texels,
+// lambda = 0.5 * log2(max(|d(uv*size)/dx|^2, |d(uv*size)/dy|^2)) clamped to [0, levels - 1].
+template <bool MIPS>
+__device__ __forceinline__ f4 sample_texture(DrawRef D, int slot, float u, float v, const UvGrad& g) {
+    const uint32_t w = D.tex_w[slot], h = D.tex_h[slot], levels = D.tex_levels[slot];
+    const uint32_t* texels = reinterpret_cast<const uint32_t*>(D.tex[slot]);
+    if (!texels || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
+    const bool srgb = MIPS && ((D.tex_srgb >> slot) & 1u);      // (sRGB and mip-mapped textures live in the full-featured variant)
+    if (!MIPS || levels <= 1u) return sample_level(texels, w, h, u, v, srgb);
+    const float ax = g.dudx * (float)w, bx = g.dvdx * (float)h, ay = g.dudy * (float)w, by = g.dvdy * (float)h;
+    const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+    float lam = 0.5f * __builtin_amdgcn_logf(rx > ry ? rx : ry);          // v_log_f32 is log2
+    if (!(lam > 0.0f)) lam = 0.0f;                                        // magnification, zero footprint, NaN
+    const float top = (float)(levels - 1u);
+    if (lam > top) lam = top;
+    const float l0f = floorf(lam), f = lam - l0f;
+    const uint32_t l0 = (uint32_t)l0f;
+    uint32_t lw = w, lh = h;
+    for (uint32_t l = 0; l < l0; l++) { texels += (size_t)lw * lh; lw = lw > 1u ? lw >> 1 : 1u; lh = lh > 1u ? lh >> 1 : 1u; }
+    const f4 c0 = sample_level(texels, lw, lh, u, v, srgb);
+    if (l0 + 1u >= levels) return c0;
+    const uint32_t* next = texels + (size_t)lw * lh;
+    const f4 c1 = sample_level(next, lw > 1u ? lw >> 1 : 1u, lh > 1u ? lh >> 1 : 1u, u, v, srgb);
+    return {c0.x + (c1.x - c0.x) * f, c0.y + (c1.y - c0.y) * f, c0.z + (c1.z - c0.z) * f, c0.w + (c1.w - c0.w) * f};
 }
 
 #pragma clang fp contract(off)
@@ -168,7 +199,7 @@ __device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const Pb
 }
 
 // pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
-__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyings vv[3], f3 worldPos, f3 V, f3 N) {
+__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyings vv[3], f3 worldPos, f3 V, f3 N, const UvGrad& grad) {
     const CBytePtr M = cb(D.material);                                                  // MaterialData :36-59 (80 B)
     const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
@@ -177,20 +208,20 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
     const float normalScale = ldcf(M, 28);
     f3 emissive = {ldcf(M, 32), ldcf(M, 36), ldcf(M, 40)};
     if (ldcu(M, 48) != 0u) {
-        const f4 t = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+        const f4 t = sample_texture<true>(D, 0, u, v, grad);
         baseColor = {t.x * baseColor.x, t.y * baseColor.y, t.z * baseColor.z, t.w * baseColor.w};
     }
     if (ldcu(M, 56) != 0u) {
-        const f4 t = sample_bilinear(D.tex[2], D.tex_w[2], D.tex_h[2], u, v);
+        const f4 t = sample_texture<true>(D, 2, u, v, grad);
         roughness = roughness * t.y; metallic = metallic * t.z;
     }
-    if (ldcu(M, 60) != 0u) ao = ao * sample_bilinear(D.tex[3], D.tex_w[3], D.tex_h[3], u, v).x;
+    if (ldcu(M, 60) != 0u) ao = ao * sample_texture<true>(D, 3, u, v, grad).x;
     if (ldcu(M, 64) != 0u) {
-        const f4 t = sample_bilinear(D.tex[4], D.tex_w[4], D.tex_h[4], u, v);
+        const f4 t = sample_texture<true>(D, 4, u, v, grad);
         emissive = {emissive.x * t.x, emissive.y * t.y, emissive.z * t.z};
     }
     if (ldcu(M, 52) != 0u) {                                                            // GetWorldNormal :124-151
-        const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+        const f4 nc = sample_texture<true>(D, 1, u, v, grad);
         const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
         if (!(length3(ncm1) < 0.01f)) {
             const f3 ns = normalize3({(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f});
@@ -249,7 +280,8 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
     return {col.x, col.y, col.z, baseColor.w};
 }
 
-template <bool PBR>
+// FULL: the variant that also carries the Cook-Torrance program and mip-mapped (trilinear) sampling
+template <bool FULL>
 __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     f4 c[3]; Varyings vv[3];
     const bool full = D.program >= 2;
@@ -286,15 +318,28 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
         const f3 col = add3(ambient, lighting);
         return {col.x, col.y, col.z, 1.0f};
     }
-    if (PBR && D.program == 3) return shade_pbr(D, b, vv, worldPos, V, N);
+    // Mip-mapped textures need the screen-space footprint of (u, v): the same perspective-correct interpolation one pixel
+    // to the right and one pixel down (exact for a planar triangle; no quad, no neighbour lane needed)
+    UvGrad grad = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (FULL && D.tex_any_mips) {
+        const float u0 = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u, v0 = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
+        float bx[3], by[3];
+        barycentrics<false>(D, c, pxc + 1.0f, pyc, bx);
+        barycentrics<false>(D, c, pxc, pyc + 1.0f, by);
+        grad.dudx = ((bx[0] * vv[0].u + bx[1] * vv[1].u) + bx[2] * vv[2].u) - u0;
+        grad.dvdx = ((bx[0] * vv[0].v + bx[1] * vv[1].v) + bx[2] * vv[2].v) - v0;
+        grad.dudy = ((by[0] * vv[0].u + by[1] * vv[1].u) + by[2] * vv[2].u) - u0;
+        grad.dvdy = ((by[0] * vv[0].v + by[1] * vv[1].v) + by[2] * vv[2].v) - v0;
+    }
+    if (FULL && D.program == 3) return shade_pbr(D, b, vv, worldPos, V, N, grad);
     // pixel/model_full.hlsl:85-150
     const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
     const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
     const f4 baseColor = {ldcf(cb(D.material), 0), ldcf(cb(D.material), 4), ldcf(cb(D.material), 8), ldcf(cb(D.material), 12)};
     const float roughness = ldcf(cb(D.material), 20), ao = ldcf(cb(D.material), 24);
-    const f4 albedoSample = sample_bilinear(D.tex[0], D.tex_w[0], D.tex_h[0], u, v);
+    const f4 albedoSample = sample_texture<FULL>(D, 0, u, v, grad);
     const f3 albedo = {albedoSample.x * baseColor.x, albedoSample.y * baseColor.y, albedoSample.z * baseColor.z};
-    const f4 nc = sample_bilinear(D.tex[1], D.tex_w[1], D.tex_h[1], u, v);
+    const f4 nc = sample_texture<FULL>(D, 1, u, v, grad);
     const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
     const bool hasNormalMap = length3(ncm1) > 0.01f;                          // :94-95
     if (hasNormalMap) {                                                      // GetWorldNormal :63-83

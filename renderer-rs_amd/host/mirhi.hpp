@@ -236,7 +236,7 @@ private:
     mirhi_buffer* h_ = nullptr;
 };
 
-enum class Format { Undefined = 0, B8G8R8A8_SRGB, R32G32B32A32_SFLOAT, D32_SFLOAT, R8G8B8A8_UNORM, R32_UINT };
+enum class Format { Undefined = 0, B8G8R8A8_SRGB, R32G32B32A32_SFLOAT, D32_SFLOAT, R8G8B8A8_UNORM, R32_UINT, R8G8B8A8_SRGB };
 
 class Image {
 public:
@@ -252,6 +252,8 @@ public:
     Format format() const { return f_; }
     void read(void* dst) const { check(mirhi_image_read(h_, dst, mirhi_image_size_bytes(h_))); }
     void upload(const void* src) const { check(mirhi_image_upload(h_, src, mirhi_image_size_bytes(h_))); }
+    void generate_mips() const { check(mirhi_image_generate_mips(h_)); }     // texture fidelity
+    uint32_t mip_levels() const { return mirhi_image_mip_levels(h_); }
 private:
     std::shared_ptr<Device> device_;
     mirhi_image* h_ = nullptr;

@@ -184,6 +184,8 @@ def spot_light(position, inner_cos, direction, outer_cos, color, intensity) -> b
 @dataclass
 class Texture:
     rgba8: np.ndarray  # (h, w, 4) uint8
+    mips: bool = False  # sampled trilinearly through a full mip chain (mirhi_image_generate_mips / mip_chain below)
+    srgb: bool = False  # R8G8B8A8_SRGB: the RGB bytes are decoded to linear when sampled
 
     @property
     def width(self):
@@ -192,6 +194,21 @@ class Texture:
     @property
     def height(self):
         return int(self.rgba8.shape[0])
+
+
+def mip_chain(rgba8: np.ndarray) -> List[np.ndarray]:
+    """Full mip chain of an (h, w, 4) uint8 image, level 0 first: 2x2 box filter on the stored bytes, round half up, edge clamp
+    for odd sizes -- the specification `mirhi_image_generate_mips` and the oracle's callers follow (include/mirhi.h)."""
+    levels = [np.ascontiguousarray(rgba8, dtype=np.uint8)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        src = levels[-1].astype(np.uint32)
+        h, w = src.shape[:2]
+        dh, dw = max(1, h >> 1), max(1, w >> 1)
+        y0 = np.minimum(2 * np.arange(dh), h - 1); y1 = np.minimum(2 * np.arange(dh) + 1, h - 1)
+        x0 = np.minimum(2 * np.arange(dw), w - 1); x1 = np.minimum(2 * np.arange(dw) + 1, w - 1)
+        acc = src[y0][:, x0] + src[y0][:, x1] + src[y1][:, x0] + src[y1][:, x1]
+        levels.append(((acc + 2) >> 2).astype(np.uint8))
+    return levels
 
 
 @dataclass
@@ -672,6 +689,38 @@ def pbr_spheres_case(width: int = 224, height: int = 144) -> Scene:
     return Scene("pbr-spheres", width, height, draws, clear_color=(0.02, 0.02, 0.03, 1.0))
 
 
+def mip_ground_case(width: int = 240, height: int = 150) -> Scene:
+    """Texture fidelity: a ground plane receding to the horizon under a fine checker -- strong, anisotropic
+    minification -- through a mip chain with trilinear filtering and an sRGB-encoded albedo, plus an upright quad that is
+    magnified (lambda clamps to 0).  A non-power-of-two normal map exercises the odd-size rule of the chain."""
+    rng = PCG32(0x717)
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = (((xx // 2) + (yy // 2)) & 1).astype(np.uint8)
+    alb = np.zeros((n, n, 4), dtype=np.uint8)
+    alb[..., 0] = 40 + 190 * checker; alb[..., 1] = 60 + 150 * (1 - checker); alb[..., 2] = 90 + (xx * 2).astype(np.uint8); alb[..., 3] = 255
+    nm = np.zeros((24, 40, 4), dtype=np.uint8)
+    r = rng.uniform(24 * 40 * 2).reshape(24, 40, 2)
+    nm[..., 0] = (128 + (r[..., 0] - 0.5) * 70).astype(np.uint8); nm[..., 1] = (128 + (r[..., 1] - 0.5) * 70).astype(np.uint8)
+    nm[..., 2] = 235; nm[..., 3] = 255
+    albedo, normal = Texture(alb, mips=True, srgb=True), Texture(nm, mips=True)
+    view, proj, cam = default_camera(width, height, eye=(0.0, 1.2, 4.0), target=(0.0, 0.3, 0.0))
+    light = light_ubo(direction=(0.2, -1.0, -0.3), intensity=0.9, color=(1.0, 0.97, 0.9), num_point=1)
+    points = point_light((1.0, 2.0, 1.5), 12.0, (0.8, 0.9, 1.0), 5.0)
+    ground = _pack_vertex48(np.array([[-30, 0, 6], [30, 0, 6], [30, 0, -120], [-30, 0, -120]], dtype=f32),
+                            np.tile(np.array([0, 1, 0], dtype=f32), (4, 1)),
+                            np.array([[0, 0], [40, 0], [40, 84], [0, 84]], dtype=f32), np.tile(np.array([1, 0, 0, 1], dtype=f32), (4, 1)))
+    wall = _pack_vertex48(np.array([[-0.6, 0.0, 1.5], [0.6, 0.0, 1.5], [0.6, 1.2, 1.5], [-0.6, 1.2, 1.5]], dtype=f32),
+                          np.tile(np.array([0, 0, 1], dtype=f32), (4, 1)),
+                          np.array([[0.1, 0.1], [0.3, 0.1], [0.3, 0.3], [0.1, 0.3]], dtype=f32), np.tile(np.array([1, 0, 0, 1], dtype=f32), (4, 1)))
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    common = dict(stride=48, count=6, indices=idx, program=PROGRAM_MODEL_FULL, cull_mode=CULL_NONE, camera=cam,
+                  object=object_ubo(np.eye(4, dtype=f32)), light=light, point_lights=points,
+                  material=material_ubo((1.0, 1.0, 1.0, 1.0), 0.0, 0.6, 0.9), albedo_map=albedo, normal_map=normal)
+    return Scene("mip-ground", width, height, [DrawSpec(vertices=ground, **common), DrawSpec(vertices=wall, **common)],
+                 clear_color=(0.3, 0.5, 0.8, 1.0))
+
+
 def gltf_model(path: str, width: int = 1920, height: int = 1080, program: int = PROGRAM_MODEL_FULL,
                eye=(0.0, 0.0, 3.2), yaw: float = 0.4) -> Scene:
     """A glTF asset through the reference's loader semantics (gltf.load) -> `Vertex` streams, lit like config 3:
@@ -702,6 +751,7 @@ SMALL_CASES = {
     "huge": huge_triangle_case,
     "textured": textured_quad_case,
     "pbr": pbr_spheres_case,
+    "mips": mip_ground_case,
     "random_small": lambda: random_triangles(300, 320, 200, seed=42, rmin=2, rmax=40),
     "sphere_small": lambda: displaced_sphere(24, 17, 256, 160, seed=3),
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(ORACLE_DIR, "libmirhi_oracle.so")
 
 
 class OracleTexture(C.Structure):
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32), ("srgb", C.c_uint32)]
 
 
 class OracleDraw(C.Structure):
@@ -119,9 +119,15 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
                           ("metallic_roughness_map", d.metallic_roughness_map), ("occlusion_map", d.occlusion_map),
                           ("emissive_map", d.emissive_map)):
             if tex is not None:
+                levels = 1
                 arr = np.ascontiguousarray(tex.rgba8)
+                if getattr(tex, "mips", False):        # the chain is built here, by numpy, independently of the HIP mip kernel
+                    from renderer_rs_amd.scenes import mip_chain
+                    chain = mip_chain(tex.rgba8)
+                    levels = len(chain)
+                    arr = np.concatenate([l.reshape(-1) for l in chain])
                 keep.append(arr)
-                t = OracleTexture(arr.ctypes.data, tex.width, tex.height)
+                t = OracleTexture(arr.ctypes.data, tex.width, tex.height, levels, int(getattr(tex, "srgb", False)))
                 setattr(od, name, t)
     p = OraclePass()
     p.width, p.height = scene.width, scene.height

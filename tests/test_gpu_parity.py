@@ -43,14 +43,14 @@ def _check(out, ref, name, depth=False):
 
 
 @pytest.mark.parametrize("case", ["hello", "fan", "near_clip", "depth_tie", "cull_scissor", "multi_draw", "huge",
-                                  "textured", "pbr", "random_small", "sphere_small"])
+                                  "textured", "pbr", "mips", "random_small", "sphere_small"])
 def test_small_cases_float(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, want_depth=any(d.depth_test for d in scene.draws))
     _check(out, ref, scene.name, depth=any(d.depth_test for d in scene.draws))
 
 
-@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr"])
+@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr", "mips"])
 def test_small_cases_srgb8(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, fmt=mirhi.Format.B8G8R8A8_SRGB)
@@ -164,3 +164,26 @@ def test_repeated_frames_are_identical(mirhi, oracle, device, scenes):
         out = res.read()
         assert np.array_equal(out["prim"], ref["prim"]), f"frame {it} differs from the oracle"
     res.destroy()
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 21), (1, 9), (128, 2)])
+def test_mip_chain_matches_the_stated_rule(mirhi, device, scenes, shape):
+    """mirhi_image_generate_mips against the numpy restatement of its rule (scenes.mip_chain), level by level, read back
+    through a 1:1 textured draw of each level's footprint is overkill: the chain is contiguous behind level 0, so the
+    whole allocation is read through a wrapped view."""
+    import ctypes as C
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    t = mirhi.Image(device, w, h, mirhi.Format.R8G8B8A8_UNORM)
+    t.upload(img)
+    t.generate_mips()
+    chain = scenes.mip_chain(img)
+    assert t.mip_levels == len(chain)
+    total = sum(l.size for l in chain)
+    view = mirhi.Image(device, total // 4, 1, mirhi.Format.R8G8B8A8_UNORM, device_ptr=mirhi.lib().mirhi_image_device_ptr(t.handle))
+    got = view.read().reshape(-1)
+    want = np.concatenate([l.reshape(-1) for l in chain])
+    assert np.array_equal(got, want)
+    view.destroy()
+    t.destroy()

@@ -284,3 +284,63 @@ def test_k7_pbr_alpha_cutoff(oracle, scenes):
     sc.draws[4].material = scenes.pbr_material_ubo((0.3, 0.4, 0.9, 0.6), alpha_cutoff=0.25, has_base_color=True)
     with pytest.raises(RuntimeError, match="oracle_render failed: 2"):
         oracle.render(sc)
+
+
+# ------------------------------------------------------------------------------------------------
+# K8: texture fidelity -- mip chain rule, LOD selection and sRGB decode against closed forms
+# ------------------------------------------------------------------------------------------------
+def _textured_quad_scene(scenes, tex, W, H, uv_scale):
+    """A quad filling the viewport exactly, uv = uv_scale * (0..1): texels per pixel = uv_scale * tex_size / W."""
+    pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
+    verts = np.zeros((4, 12), dtype=np.float32)
+    verts[:, 0:3] = pos; verts[:, 3:6] = [0, 0, 1]; verts[:, 8:12] = [1, 0, 0, 1]
+    verts[:, 6:8] = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32) * uv_scale
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    ident = np.eye(4, dtype=np.float32)
+    d = scenes.DrawSpec(vertices=verts, stride=48, count=6, indices=idx, program=scenes.PROGRAM_MODEL_FULL,
+                        cull_mode=scenes.CULL_NONE, depth_test=False, depth_write=False,
+                        camera=scenes.camera_ubo(ident, ident, (0.0, 0.0, 1.0)), object=scenes.object_ubo(ident),
+                        light=scenes.light_ubo(intensity=0.0), material=scenes.material_ubo((1.0, 1.0, 1.0, 1.0), 0.0, 1.0, 1.0),
+                        albedo_map=tex, normal_map=scenes.WHITE_1X1)
+    return scenes.Scene("k8", W, H, [d])
+
+
+def test_k8_mip_chain_rule(scenes):
+    """2x2 box filter on the bytes, round half up; odd sizes clamp the last row / column; the chain ends at 1x1."""
+    img = np.zeros((3, 5, 4), dtype=np.uint8)
+    img[..., 0] = np.arange(15).reshape(3, 5) * 10
+    img[..., 3] = 255
+    chain = scenes.mip_chain(img)
+    assert [l.shape[:2] for l in chain] == [(3, 5), (1, 2), (1, 1)]
+    assert chain[1][0, 0, 0] == (0 + 10 + 50 + 60 + 2) // 4 and chain[1][0, 1, 0] == (20 + 30 + 70 + 80 + 2) // 4
+    assert chain[2][0, 0, 0] == (int(chain[1][0, 0, 0]) * 2 + int(chain[1][0, 1, 0]) * 2 + 2) // 4
+    assert all(l[..., 3].min() == 255 for l in chain)
+
+
+@pytest.mark.parametrize("texels_per_pixel,expect_level", [(1.0, 0.0), (2.0, 1.0), (4.0, 2.0), (0.25, 0.0)])
+def test_k8_lod_selects_the_level_whose_texel_matches_the_pixel(oracle, scenes, texels_per_pixel, expect_level):
+    """With n texels per pixel lambda = log2(n): a 1-texel checker is resolved at level 0 and becomes its mean from level 1
+    on (every 2x2 block of the checker averages to the same grey); the ambient term 0.03 * albedo * ao is the only light."""
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    tex = np.zeros((n, n, 4), dtype=np.uint8)
+    tex[..., 0:3] = (255 * ((xx + yy) & 1))[..., None]
+    tex[..., 3] = 255
+    W = H = 64
+    sc = _textured_quad_scene(scenes, scenes.Texture(tex, mips=True), W, H, uv_scale=texels_per_pixel * W / n)
+    out = oracle.render(sc)["rgba"][8:56, 8:56, 0] / 0.03      # ambient = albedo * 0.03 * ao(1)
+    if expect_level >= 1.0:
+        assert np.allclose(out, 128.0 / 255.0, atol=1e-5)       # (0 + 255 + 255 + 0 + 2) >> 2 = 128 on every coarser level
+    else:
+        assert out.min() < 0.3 and out.max() > 0.7              # the checker is still resolved (bilinear between texels)
+
+
+def test_k8_srgb_decode(oracle, scenes):
+    tex = np.zeros((1, 1, 4), dtype=np.uint8)
+    for byte in (0, 10, 11, 128, 200, 255):
+        tex[0, 0] = (byte, byte, byte, 255)
+        sc = _textured_quad_scene(scenes, scenes.Texture(tex.copy(), srgb=True), 8, 8, 1.0)
+        got = float(oracle.render(sc)["rgba"][4, 4, 0]) / 0.03
+        c = byte / 255.0
+        want = c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
+        assert got == pytest.approx(want, rel=2e-6, abs=1e-8), byte
