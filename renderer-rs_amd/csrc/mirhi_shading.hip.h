@@ -135,30 +135,28 @@ __device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc
     b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
 }
 
-#pragma clang fp contract(fast)
-// vertex/triangle.hlsl + pixel/triangle.hlsl: clip = (pos, 1), colour pass-through.  No pow downstream, so FMA
-// contraction and the 1-ulp rcp stay ~1e-7 from the oracle (bound 1e-4).  With w = 1 the homogeneous
-// barycentrics reduce to ax_k = x_k * W/2 + (cx - px).
+// vertex/triangle.hlsl + pixel/triangle.hlsl: clip = (pos, 1), colour pass-through.  Strict arithmetic in the oracle's
+// operation order: for a sliver triangle the three lambdas nearly cancel, and a contracted FMA or the 1-ulp rcp then shows
+// up as 1e-3 in the interpolated colour (found by the 60000-scene soak of tools/soak_fuzz.py; one pixel in ~3000 scenes).
+// With w = 1 the homogeneous form is ax_k = (x_k * W/2 + cx) - px.  Flat-coloured triangles never get here (flat_color).
 __device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
     float ax[3], ay[3]; f3 col[3];
-    const float tx = D.cx - pxc, ty = D.cy - pyc;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         const uint32_t vidx = fetch_index(D, 3u * tri + k);
         const uint8_t* v = D.vb + (size_t)vidx * D.stride;
-        ax[k] = ldf(v, 0) * D.hw + tx;                                       // vertex/triangle.hlsl:19-20
-        ay[k] = ldf(v, 4) * D.hh + ty;
+        ax[k] = (ldf(v, 0) * D.hw + D.cx) - pxc;                             // vertex/triangle.hlsl:19-20
+        ay[k] = (ldf(v, 4) * D.hh + D.cy) - pyc;
         col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
     }
     const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
     const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
     const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
-    const float inv = __builtin_amdgcn_rcpf((l0 + l1) + l2);
+    const float inv = 1.0f / ((l0 + l1) + l2);
     const float b[3] = {l0 * inv, l1 * inv, l2 * inv};
     const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
     return {o.x, o.y, o.z, 1.0f};
 }
-#pragma clang fp contract(off)
 
 // a8: Cook-Torrance GGX, shaders/hlsl/pbr.hlsli (shadow pass not on the path: shadow = 1)
 #define PBR_PI 3.14159265358979323846f

@@ -19,8 +19,8 @@ def _random_scene(scenes, seed):
         front = int(rng.integers(0, 2))
         cmp_ = [scenes.CMP_LESS, scenes.CMP_LESS_OR_EQUAL, scenes.CMP_GREATER, scenes.CMP_GREATER_OR_EQUAL][int(rng.integers(0, 4))]
         if rng.random() < 0.3:
-            vp = (float(rng.integers(-20, 20)), float(rng.integers(-20, 20)), float(W + rng.integers(-30, 40)), float(H + rng.integers(-20, 30)),
-                  float(rng.uniform(0, 0.3)), float(rng.uniform(0.6, 1.0)))
+            vp = (float(rng.integers(-20, 20)), float(rng.integers(-20, 20)), float(W + rng.integers(-30, 40)), float(H + rng.integers(-20, 30)) or 1.0,
+                  float(rng.uniform(0, 0.3)), float(rng.uniform(0.6, 1.0)))      # (a negative height flips y: legal; 0 is not)
         else:
             vp = None
         sc = (int(rng.integers(0, W // 3)), int(rng.integers(0, H // 3)), int(rng.integers(W // 3, W)), int(rng.integers(H // 3, H))) if rng.random() < 0.3 else None
