@@ -110,8 +110,9 @@ def _random_pbr_scene(scenes, seed):
     rng = np.random.default_rng(seed)
     W, H = int(rng.integers(40, 260)), int(rng.integers(30, 200))
 
-    def tex(n):
-        return scenes.Texture(rng.integers(0, 256, (n, n, 4), dtype=np.uint8))
+    def tex(n):        # square or not, a third with a mip chain (trilinear), a third sRGB-encoded
+        return scenes.Texture(rng.integers(0, 256, (n, int(rng.integers(1, 24)) if rng.random() < 0.3 else n, 4), dtype=np.uint8),
+                              mips=bool(rng.random() < 0.35), srgb=bool(rng.random() < 0.35))
 
     eye = (float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(1.2, 4.0)))
     view = scenes.look_at_rh(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
@@ -192,3 +193,29 @@ def test_fuzz_predicate_depth_states(mirhi, oracle, device, scenes, seed):
     ref = oracle.render(scene, want_bgra8=False)
     assert np.array_equal(out["prim"], ref["prim"]), f"{scene.name} op {op} write {write}: winning primitive differs"
     assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32)), f"{scene.name} op {op} write {write}: depth differs"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, seed):
+    """Every draw of the scope gets its own depth state (any compare op, test on/off, write on/off; NotEqual only without
+    write): the scope is cut into segments at each change (DESIGN.md "Depth key") and must still equal the oracle's
+    fragment-by-fragment order."""
+    scene = _random_scene(scenes, 9000 + seed)
+    rng = np.random.default_rng(9500 + seed)
+    for d in scene.draws:
+        d.depth_test = bool(rng.random() < 0.8)
+        d.depth_compare = int(rng.integers(0, 8))
+        d.depth_write = bool(rng.random() < 0.6) and d.depth_compare != scenes.CMP_NOT_EQUAL
+    scene.clear_depth = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"]), f"{scene.name}: winning primitive differs"
+    assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32)), f"{scene.name}: depth differs"
+    a, b = out["color"], ref["rgba"]
+    nan = np.isnan(b)
+    assert np.array_equal(np.isnan(a), nan)
+    err = np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b)))
+    assert err.max() < 1e-4

@@ -21,6 +21,12 @@ for i in range(n):
             rng = np.random.default_rng(seed)
             op, write = [(o, False) for o in range(8)][int(rng.integers(0, 8))]
             for d in scene.draws: d.depth_test, d.depth_write, d.depth_compare = True, write, op
+        if kind == "state" and i % 3 == 1:      # every third one with a different depth state per draw (scope segments)
+            rng = np.random.default_rng(seed)
+            for d in scene.draws:
+                d.depth_test = bool(rng.random() < 0.8)
+                d.depth_compare = int(rng.integers(0, 8))
+                d.depth_write = bool(rng.random() < 0.6) and d.depth_compare != m.scenes.CMP_NOT_EQUAL
         try:
             res = m.SceneResources(dev, scene, want_prim=True, want_depth=True)
             res.render(); out = res.read(); res.destroy()
