@@ -139,6 +139,14 @@ typedef enum { MIRHI_FRONT_FACE_COUNTER_CLOCKWISE = 0, MIRHI_FRONT_FACE_CLOCKWIS
 typedef enum { MIRHI_COMPARE_NEVER = 0, MIRHI_COMPARE_LESS = 1, MIRHI_COMPARE_EQUAL = 2, MIRHI_COMPARE_LESS_OR_EQUAL = 3,
                MIRHI_COMPARE_GREATER = 4, MIRHI_COMPARE_NOT_EQUAL = 5, MIRHI_COMPARE_GREATER_OR_EQUAL = 6, MIRHI_COMPARE_ALWAYS = 7 } mirhi_compare_op; /* :375-409 */
 
+/* ColorBlendAttachment (pipeline.rs:478-531): BlendFactor :411-448, BlendOp :452-476, in the reference's enum order.  The
+ * CONSTANT_* factors need blend constants, which the reference's command buffer has no call for: refused at pipeline create. */
+typedef enum { MIRHI_BLEND_ZERO = 0, MIRHI_BLEND_ONE, MIRHI_BLEND_SRC_COLOR, MIRHI_BLEND_ONE_MINUS_SRC_COLOR, MIRHI_BLEND_DST_COLOR,
+               MIRHI_BLEND_ONE_MINUS_DST_COLOR, MIRHI_BLEND_SRC_ALPHA, MIRHI_BLEND_ONE_MINUS_SRC_ALPHA, MIRHI_BLEND_DST_ALPHA,
+               MIRHI_BLEND_ONE_MINUS_DST_ALPHA, MIRHI_BLEND_CONSTANT_COLOR, MIRHI_BLEND_ONE_MINUS_CONSTANT_COLOR, MIRHI_BLEND_CONSTANT_ALPHA,
+               MIRHI_BLEND_ONE_MINUS_CONSTANT_ALPHA, MIRHI_BLEND_SRC_ALPHA_SATURATE } mirhi_blend_factor;
+typedef enum { MIRHI_BLEND_OP_ADD = 0, MIRHI_BLEND_OP_SUBTRACT, MIRHI_BLEND_OP_REVERSE_SUBTRACT, MIRHI_BLEND_OP_MIN, MIRHI_BLEND_OP_MAX } mirhi_blend_op;
+
 typedef struct {
     int32_t  vertex_program;            /* builder.vertex_shader();   MIRHI_PROGRAM_NONE -> "Vertex shader is required" */
     int32_t  fragment_program;          /* builder.fragment_shader(); MIRHI_PROGRAM_NONE -> "Fragment shader is required" */
@@ -161,6 +169,11 @@ typedef struct {
     uint32_t color_attachment_count;    /* default 0 -> "At least one color attachment format is required" */
     int32_t  color_attachment_formats[4];
     int32_t  depth_attachment_format;   /* default UNDEFINED (None) :690 */
+    /* the colour attachment's ColorBlendAttachment, used when blend_enable != 0 (defaults :499-512: One, Zero, Add, One, Zero, Add,
+     * RGBA).  Blended draws are resolved fragment by fragment in primitive order (DESIGN.md "Ordered segments"). */
+    int32_t  src_color_blend_factor, dst_color_blend_factor, color_blend_op;
+    int32_t  src_alpha_blend_factor, dst_alpha_blend_factor, alpha_blend_op;
+    uint32_t color_write_mask;          /* bit 0 R, 1 G, 2 B, 3 A */
 } mirhi_pipeline_desc;
 void         mirhi_pipeline_desc_default(mirhi_pipeline_desc* desc);                      /* GraphicsPipelineBuilder::new :645-698 */
 mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pipeline_desc* desc, mirhi_pipeline** out); /* build :918-1057 */

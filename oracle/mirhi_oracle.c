@@ -697,7 +697,51 @@ typedef struct {
     uint32_t row0, row1;
     float* depth; uint32_t* prim; /* full-frame scratch, this band only touches its rows */
     float* out_rgba; uint8_t* out_bgra8;
+    float* blend_color;         /* width*height*4, only when some draw blends: the pixel's current colour */
+    uint8_t* blend_valid;       /* 1 = blend_color holds the pixel's colour; 0 = it is still the shade of prim[idx] (or the clear colour) */
 } band_job;
+
+/* ------------------------------------------------------------------------------------------------
+ * colour blending (Vulkan 1.3 section 28.1, configured by ColorBlendAttachment pipeline.rs:478-531)
+ * ---------------------------------------------------------------------------------------------- */
+static void blend_factor(uint32_t f, const float s[4], const float d[4], float rgb[3], float* a) {
+    float one_m_da = 1.0f - d[3], sat = s[3] < one_m_da ? s[3] : one_m_da;
+    switch (f) {
+        case ORACLE_BF_ZERO: rgb[0] = rgb[1] = rgb[2] = 0.0f; *a = 0.0f; break;
+        case ORACLE_BF_ONE: rgb[0] = rgb[1] = rgb[2] = 1.0f; *a = 1.0f; break;
+        case ORACLE_BF_SRC_COLOR: rgb[0] = s[0]; rgb[1] = s[1]; rgb[2] = s[2]; *a = s[3]; break;
+        case ORACLE_BF_ONE_MINUS_SRC_COLOR: rgb[0] = 1.0f - s[0]; rgb[1] = 1.0f - s[1]; rgb[2] = 1.0f - s[2]; *a = 1.0f - s[3]; break;
+        case ORACLE_BF_DST_COLOR: rgb[0] = d[0]; rgb[1] = d[1]; rgb[2] = d[2]; *a = d[3]; break;
+        case ORACLE_BF_ONE_MINUS_DST_COLOR: rgb[0] = 1.0f - d[0]; rgb[1] = 1.0f - d[1]; rgb[2] = 1.0f - d[2]; *a = 1.0f - d[3]; break;
+        case ORACLE_BF_SRC_ALPHA: rgb[0] = rgb[1] = rgb[2] = s[3]; *a = s[3]; break;
+        case ORACLE_BF_ONE_MINUS_SRC_ALPHA: rgb[0] = rgb[1] = rgb[2] = 1.0f - s[3]; *a = 1.0f - s[3]; break;
+        case ORACLE_BF_DST_ALPHA: rgb[0] = rgb[1] = rgb[2] = d[3]; *a = d[3]; break;
+        case ORACLE_BF_ONE_MINUS_DST_ALPHA: rgb[0] = rgb[1] = rgb[2] = one_m_da; *a = one_m_da; break;
+        case ORACLE_BF_SRC_ALPHA_SATURATE: rgb[0] = rgb[1] = rgb[2] = sat; *a = 1.0f; break;
+        default: rgb[0] = rgb[1] = rgb[2] = 0.0f; *a = 0.0f; break;   /* constant-colour factors: no blend constants on this path */
+    }
+}
+static float blend_op(uint32_t op, float s, float sf, float d, float df) {
+    switch (op) {
+        case ORACLE_BO_SUBTRACT: return s * sf - d * df;
+        case ORACLE_BO_REVERSE_SUBTRACT: return d * df - s * sf;
+        case ORACLE_BO_MIN: return s < d ? s : d;
+        case ORACLE_BO_MAX: return s > d ? s : d;
+        default: return s * sf + d * df;
+    }
+}
+static void blend_pixel(const oracle_draw* dr, const float s[4], float d[4]) {
+    float sc[3], dc[3], sa, da, tmp;
+    blend_factor(dr->src_color_factor, s, d, sc, &tmp);
+    blend_factor(dr->dst_color_factor, s, d, dc, &tmp);
+    float t3[3];
+    blend_factor(dr->src_alpha_factor, s, d, t3, &sa);
+    blend_factor(dr->dst_alpha_factor, s, d, t3, &da);
+    float r[4];
+    for (int k = 0; k < 3; k++) r[k] = blend_op(dr->color_op, s[k], sc[k], d[k], dc[k]);
+    r[3] = blend_op(dr->alpha_op, s[3], sa, d[3], da);
+    for (int k = 0; k < 4; k++) if (dr->color_write_mask & (1u << k)) d[k] = r[k];
+}
 
 static void* band_run(void* arg) {
     band_job* j = (band_job*)arg;
@@ -725,6 +769,25 @@ static void* band_run(void* arg) {
                 size_t idx = (size_t)y * W + (size_t)x;
                 int pass_test = d->depth_test ? depth_cmp(d->depth_compare, z, j->depth[idx]) : 1;
                 if (!pass_test) continue;
+                if (d->blend_enable) {
+                    /* the destination colour is needed now: resolve what the pixel shows so far, shade this fragment, blend */
+                    float* dst = j->blend_color + 4 * idx;
+                    if (!j->blend_valid[idx]) {
+                        uint32_t p0 = j->prim[idx];
+                        if (p0 == ORACLE_NO_PRIM) memcpy(dst, pass->clear_color, 4 * sizeof(float));
+                        else {
+                            uint32_t d0 = 0;
+                            while (d0 + 1 < pass->num_draws && j->prim_base[d0 + 1] <= p0) d0++;
+                            shade_pixel(pass, &pass->draws[d0], p0 - j->prim_base[d0], (uint32_t)x, (uint32_t)y, dst);
+                        }
+                        j->blend_valid[idx] = 1;
+                    }
+                    float src[4];
+                    shade_pixel(pass, d, t->prim - j->prim_base[t->draw], (uint32_t)x, (uint32_t)y, src);
+                    blend_pixel(d, src, dst);
+                } else if (j->blend_valid) {
+                    j->blend_valid[idx] = 0;         /* opaque overwrite: the pixel is the shade of this primitive again */
+                }
                 j->prim[idx] = t->prim;
                 if (d->depth_test && d->depth_write) j->depth[idx] = z;
             }
@@ -736,7 +799,9 @@ static void* band_run(void* arg) {
             size_t idx = (size_t)y * W + x;
             float rgba[4];
             uint32_t p = j->prim[idx];
-            if (p == ORACLE_NO_PRIM) {
+            if (j->blend_valid && j->blend_valid[idx]) {
+                memcpy(rgba, j->blend_color + 4 * idx, sizeof rgba);
+            } else if (p == ORACLE_NO_PRIM) {
                 memcpy(rgba, pass->clear_color, sizeof rgba);
             } else {
                 uint32_t di = 0;
@@ -799,6 +864,10 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
     }
     if (nthreads < 1) nthreads = 1;
     if ((uint32_t)nthreads > r1 - r0) nthreads = (int)(r1 - r0);
+    int any_blend = 0;
+    for (uint32_t di = 0; di < pass->num_draws; di++) any_blend |= pass->draws[di].blend_enable != 0;
+    float* blend_color = any_blend ? (float*)malloc(npix * 4 * sizeof(float)) : NULL;
+    uint8_t* blend_valid = any_blend ? (uint8_t*)calloc(npix, 1) : NULL;
     band_job* jobs = (band_job*)calloc((size_t)nthreads, sizeof(band_job));
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     uint32_t rows = r1 - r0;
@@ -808,11 +877,13 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
         j->row0 = r0 + (uint32_t)(((uint64_t)rows * (uint64_t)i) / (uint64_t)nthreads);
         j->row1 = r0 + (uint32_t)(((uint64_t)rows * (uint64_t)(i + 1)) / (uint64_t)nthreads);
         j->depth = depth; j->prim = prim; j->out_rgba = out_rgba; j->out_bgra8 = out_bgra8;
+        j->blend_color = blend_color; j->blend_valid = blend_valid;
         if (nthreads == 1) band_run(j);
         else pthread_create(&th[i], NULL, band_run, j);
     }
     if (nthreads > 1) for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
     free(jobs); free(th);
+    free(blend_color); free(blend_valid);
     if (!out_depth) free(depth);
     if (!out_prim) free(prim);
     free(prim_base);

@@ -36,6 +36,11 @@ extern "C" {
 enum { ORACLE_PROGRAM_TRIANGLE = 0, ORACLE_PROGRAM_MODEL = 1, ORACLE_PROGRAM_MODEL_FULL = 2, ORACLE_PROGRAM_MODEL_PBR = 3 };
 enum { ORACLE_CULL_NONE = 0, ORACLE_CULL_FRONT = 1, ORACLE_CULL_BACK = 2, ORACLE_CULL_FRONT_AND_BACK = 3 };
 enum { ORACLE_FRONT_CCW = 0, ORACLE_FRONT_CW = 1 };
+/* pipeline.rs:411-448 BlendFactor order, :452-476 BlendOp order */
+enum { ORACLE_BF_ZERO = 0, ORACLE_BF_ONE, ORACLE_BF_SRC_COLOR, ORACLE_BF_ONE_MINUS_SRC_COLOR, ORACLE_BF_DST_COLOR, ORACLE_BF_ONE_MINUS_DST_COLOR,
+       ORACLE_BF_SRC_ALPHA, ORACLE_BF_ONE_MINUS_SRC_ALPHA, ORACLE_BF_DST_ALPHA, ORACLE_BF_ONE_MINUS_DST_ALPHA, ORACLE_BF_CONSTANT_COLOR,
+       ORACLE_BF_ONE_MINUS_CONSTANT_COLOR, ORACLE_BF_CONSTANT_ALPHA, ORACLE_BF_ONE_MINUS_CONSTANT_ALPHA, ORACLE_BF_SRC_ALPHA_SATURATE };
+enum { ORACLE_BO_ADD = 0, ORACLE_BO_SUBTRACT, ORACLE_BO_REVERSE_SUBTRACT, ORACLE_BO_MIN, ORACLE_BO_MAX };
 /* crates/rhi/src/pipeline.rs:375-409 CompareOp order */
 enum { ORACLE_CMP_NEVER = 0, ORACLE_CMP_LESS = 1, ORACLE_CMP_EQUAL = 2, ORACLE_CMP_LESS_OR_EQUAL = 3,
        ORACLE_CMP_GREATER = 4, ORACLE_CMP_NOT_EQUAL = 5, ORACLE_CMP_GREATER_OR_EQUAL = 6, ORACLE_CMP_ALWAYS = 7 };
@@ -76,6 +81,11 @@ typedef struct {
     oracle_texture albedo_map, normal_map;
     /* MODEL_PBR only (pixel/model_pbr.hlsl:62-95): t2 metallic-roughness, t3 occlusion, t4 emissive; material is the 80 B block :36-59 */
     oracle_texture metallic_roughness_map, occlusion_map, emissive_map;
+    /* colour blending (ColorBlendAttachment, crates/rhi/src/pipeline.rs:478-531; factors :411-448, ops :452-476).
+     * blend_enable 0: opaque overwrite.  Fragments are blended in primitive order, in float, against the pixel's
+     * current colour.  Factor / op values are the reference's enum order. */
+    uint32_t blend_enable;
+    uint32_t src_color_factor, dst_color_factor, color_op, src_alpha_factor, dst_alpha_factor, alpha_op, color_write_mask;
 } oracle_draw;
 
 typedef struct {

@@ -60,6 +60,15 @@ class CompareOp:  # pipeline.rs:375-386
     Never, Less, Equal, LessOrEqual, Greater, NotEqual, GreaterOrEqual, Always = range(8)
 
 
+class BlendFactor:  # pipeline.rs:411-448
+    (Zero, One, SrcColor, OneMinusSrcColor, DstColor, OneMinusDstColor, SrcAlpha, OneMinusSrcAlpha, DstAlpha, OneMinusDstAlpha,
+     ConstantColor, OneMinusConstantColor, ConstantAlpha, OneMinusConstantAlpha, SrcAlphaSaturate) = range(15)
+
+
+class BlendOp:  # pipeline.rs:452-476
+    Add, Subtract, ReverseSubtract, Min, Max = range(5)
+
+
 class LoadOp:
     LOAD, CLEAR, DONT_CARE = range(3)
 
@@ -98,6 +107,9 @@ class PipelineDesc(C.Structure):
         ("depth_compare_op", C.c_int32), ("blend_enable", C.c_uint32), ("blend_attachment_count", C.c_uint32),
         ("color_attachment_count", C.c_uint32), ("color_attachment_formats", C.c_int32 * 4),
         ("depth_attachment_format", C.c_int32),
+        ("src_color_blend_factor", C.c_int32), ("dst_color_blend_factor", C.c_int32), ("color_blend_op", C.c_int32),
+        ("src_alpha_blend_factor", C.c_int32), ("dst_alpha_blend_factor", C.c_int32), ("alpha_blend_op", C.c_int32),
+        ("color_write_mask", C.c_uint32),
     ]
 
 
@@ -448,6 +460,19 @@ class GraphicsPipelineBuilder:
         self.desc.blend_enable = int(e)
         return self
 
+    def color_blend_attachment(self, src_color, dst_color, color_op, src_alpha, dst_alpha, alpha_op, write_mask=0xF):
+        """ColorBlendAttachment (pipeline.rs:478-531) with blending enabled."""
+        d = self.desc
+        d.blend_enable = 1
+        d.src_color_blend_factor, d.dst_color_blend_factor, d.color_blend_op = src_color, dst_color, color_op
+        d.src_alpha_blend_factor, d.dst_alpha_blend_factor, d.alpha_blend_op = src_alpha, dst_alpha, alpha_op
+        d.color_write_mask = write_mask
+        return self
+
+    def alpha_blend(self):
+        """ColorBlendAttachment::alpha_blend() (pipeline.rs:518-529): src * src_alpha + dst * (1 - src_alpha)."""
+        return self.color_blend_attachment(BlendFactor.SrcAlpha, BlendFactor.OneMinusSrcAlpha, BlendOp.Add, BlendFactor.One, BlendFactor.Zero, BlendOp.Add)
+
     def color_attachment_format(self, fmt: int):
         n = self.desc.color_attachment_count
         self.desc.color_attachment_formats[n] = fmt
@@ -635,6 +660,8 @@ class SceneResources:
                  .depth_test_enable(d.depth_test).depth_write_enable(d.depth_write).depth_compare_op(d.depth_compare))
             if d.depth_test or d.depth_write:
                 b.depth_attachment_format(Format.D32_SFLOAT)
+            if getattr(d, "blend", None) is not None:
+                b.color_blend_attachment(*d.blend)
             pipe = b.build(device)
             self.objs.append(pipe)
             st = dict(pipe=pipe, vb=buf(BufferUsage.Vertex, d.vertices),

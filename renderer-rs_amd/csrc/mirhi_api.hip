@@ -127,6 +127,7 @@ struct RecordedPass {
     uint32_t total_tris = 0;
     bool key_set = false;
     uint32_t depth_test = 0, depth_compare = 0, depth_write = 0;
+    uint32_t blend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
     // a scope whose pipelines change the depth state is continued in a new segment: colour is kept (LOAD), depth is
     // carried through the depth attachment or, without one, a transient buffer of the workspace
     uint32_t first_tri = 0;                // primitive ids continue across the segments of a scope
@@ -141,6 +142,7 @@ struct Workspace {
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
     float* carry_depth = nullptr; size_t carry_depth_bytes = 0;   // depth hand-over between the segments of a scope without a depth attachment
+    TriRec* ordered = nullptr; size_t ordered_bytes = 0;          // slot t = triangle t of an ordered segment (blending)
     PassParams* params = nullptr; size_t params_bytes = 0;   // two copies per scope (big-list counter parity 0 / 1), read by the kernels
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
@@ -525,6 +527,9 @@ extern "C" void mirhi_pipeline_desc_default(mirhi_pipeline_desc* d) {
     d->depth_write_enable = 1;
     d->depth_compare_op = MIRHI_COMPARE_LESS;
     d->depth_attachment_format = MIRHI_FORMAT_UNDEFINED;
+    d->src_color_blend_factor = MIRHI_BLEND_ONE; d->dst_color_blend_factor = MIRHI_BLEND_ZERO; d->color_blend_op = MIRHI_BLEND_OP_ADD;   // pipeline.rs:499-512
+    d->src_alpha_blend_factor = MIRHI_BLEND_ONE; d->dst_alpha_blend_factor = MIRHI_BLEND_ZERO; d->alpha_blend_op = MIRHI_BLEND_OP_ADD;
+    d->color_write_mask = 0xFu;
 }
 
 extern "C" mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pipeline_desc* d, mirhi_pipeline** out) {
@@ -557,12 +562,17 @@ extern "C" mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pip
     if (d->cull_mode < 0 || d->cull_mode > 3 || d->front_face < 0 || d->front_face > 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid cull mode / front face");
     if (d->depth_compare_op < 0 || d->depth_compare_op > 7) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid depth compare op %d", d->depth_compare_op);
     if (d->rasterization_samples != 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported sample count %u", d->rasterization_samples);
-    if (d->blend_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: blending (opaque overwrite only)");
+    if (d->blend_enable) {
+        const int32_t f[4] = {d->src_color_blend_factor, d->dst_color_blend_factor, d->src_alpha_blend_factor, d->dst_alpha_blend_factor};
+        for (int32_t v : f) {
+            if (v < 0 || v > MIRHI_BLEND_SRC_ALPHA_SATURATE) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid blend factor %d", v);
+            if (v >= MIRHI_BLEND_CONSTANT_COLOR && v <= MIRHI_BLEND_ONE_MINUS_CONSTANT_ALPHA)
+                return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: constant-colour blend factors (no blend constants on this path)");
+        }
+        if (d->color_blend_op < 0 || d->color_blend_op > MIRHI_BLEND_OP_MAX || d->alpha_blend_op < 0 || d->alpha_blend_op > MIRHI_BLEND_OP_MAX)
+            return fail(MIRHI_ERR_PIPELINE, "Pipeline error: invalid blend op");
+    }
     if (d->depth_clamp_enable || d->depth_bias_enable) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth clamp / depth bias");
-    // NotEqual with depth write makes the stored depth depend on the order of ALL fragments of a pixel, passing or not: it
-    // cannot be resolved by a per-pixel minimum (DESIGN.md "Depth key") and is refused rather than drawn wrong
-    if (d->depth_test_enable && d->depth_write_enable && d->depth_compare_op == MIRHI_COMPARE_NOT_EQUAL)
-        return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: depth compare NotEqual together with depth write");
     const uint32_t want_stride = vs_model ? 48u : 24u;      // vertex.rs:35-41 / :130-136
     if (d->vertex_stride < want_stride || (d->vertex_stride & 3u))
         return fail(MIRHI_ERR_PIPELINE, "Pipeline error: vertex stride %u too small for program %d (needs >= %u, multiple of 4)", d->vertex_stride, d->vertex_program, want_stride);
@@ -606,6 +616,7 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.vs_jobs) (void)hipFree(w.vs_jobs);
     if (w.params) (void)hipFree(w.params);
     if (w.carry_depth) (void)hipFree(w.carry_depth);
+    if (w.ordered) (void)hipFree(w.ordered);
     if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.flat_color) (void)hipFree(w.flat_color);
     if (w.status_host) (void)hipHostFree(w.status_host);
@@ -769,10 +780,18 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     const uint32_t tri_count = count / 3u;
     if (instance_count == 0 || tri_count == 0) return MIRHI_OK;
     if (never) { cmd->passes.back().total_tris += tri_count; return MIRHI_OK; }     // draws nothing, but its primitives keep their ids
+    uint32_t blend[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pd.blend_enable) {
+        blend[0] = 1; blend[1] = (uint32_t)pd.src_color_blend_factor; blend[2] = (uint32_t)pd.dst_color_blend_factor; blend[3] = (uint32_t)pd.color_blend_op;
+        blend[4] = (uint32_t)pd.src_alpha_blend_factor; blend[5] = (uint32_t)pd.dst_alpha_blend_factor; blend[6] = (uint32_t)pd.alpha_blend_op;
+        blend[7] = pd.color_write_mask & 0xFu;
+    }
     if (!cmd->passes.back().key_set) {
         RecordedPass& p0 = cmd->passes.back();
         p0.key_set = true; p0.depth_test = dtest; p0.depth_compare = dcmp; p0.depth_write = dwrite;
-    } else if (cmd->passes.back().depth_test != dtest || cmd->passes.back().depth_compare != dcmp || cmd->passes.back().depth_write != dwrite) {
+        memcpy(p0.blend, blend, sizeof blend);
+    } else if (cmd->passes.back().depth_test != dtest || cmd->passes.back().depth_compare != dcmp || cmd->passes.back().depth_write != dwrite ||
+               memcmp(cmd->passes.back().blend, blend, sizeof blend) != 0) {
         // One raster launch resolves one depth state (DESIGN.md "Depth key"): the scope continues in a new segment that
         // loads what the previous one stored -- fragments keep their submission order across the cut.
         RecordedPass next;
@@ -786,6 +805,7 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
             next.first_tri = next.total_tris = prev.total_tris;
         }
         next.key_set = true; next.depth_test = dtest; next.depth_compare = dcmp; next.depth_write = dwrite;
+        memcpy(next.blend, blend, sizeof blend);
         cmd->passes.push_back(std::move(next));
     }
     RecordedPass& pass = cmd->passes.back();
@@ -880,6 +900,12 @@ static mirhi_result grow(T** ptr, size_t* have, size_t want_bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc(%zu) for rasterizer workspace: %s", want_bytes, hipGetErrorString(e)); }
     *ptr = (T*)p; *have = want_bytes;
     return MIRHI_OK;
+}
+
+// A segment is resolved fragment by fragment in primitive order (ordered_kernel) when its colour is blended, or when its
+// depth state makes the stored depth depend on the order of all fragments (NotEqual with depth write).
+static bool pass_is_ordered(const RecordedPass& pass) {
+    return pass.key_set && (pass.blend[0] != 0 || (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL));
 }
 
 static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
@@ -1012,6 +1038,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             }
         if (carry && (r = grow(&w.carry_depth, &w.carry_depth_bytes, carry)) != MIRHI_OK) return r;
     }
+    {
+        size_t ord = 0;
+        for (auto& pass : cmd->passes)
+            if (pass_is_ordered(pass)) { const size_t need = (size_t)(pass.total_tris - pass.first_tri) * sizeof(TriRec); if (need > ord) ord = need; }
+        if (ord && (r = grow(&w.ordered, &w.ordered_bytes, ord)) != MIRHI_OK) return r;
+    }
     if ((r = grow(&w.params, &w.params_bytes, (cmd->passes.size() ? cmd->passes.size() : 1) * 2 * sizeof(PassParams))) != MIRHI_OK) return r;
     std::vector<VsJob> all_jobs;
     all_jobs.reserve(jobs_total);
@@ -1038,6 +1070,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         P.num_draws = (uint32_t)pass.draws.size(); P.total_tris = pass.total_tris;
         P.draws = w.draws + all.size();
         depth_key_setup(P, pass);
+        if (pass_is_ordered(pass)) {
+            P.ordered_recs = w.ordered; P.ordered_first = pass.first_tri; P.ordered_count = pass.total_tris - pass.first_tri;
+            P.ord_depth_test = pass.depth_test; P.ord_depth_write = pass.depth_write; P.ord_depth_op = pass.depth_compare;
+            memcpy(P.blend, pass.blend, sizeof P.blend);
+            P.idflip = 0; P.pred = 0;               // records carry the plain primitive id; the kernel applies the depth state itself
+        }
         memcpy(P.clear_color, pass.info.clear_color, sizeof P.clear_color);
         {   // sRGB OETF + UNORM8 of the clear colour, BGRA byte order (swapchain.rs:561-570)
             auto sat = [](float c) { return c > 0.0f ? (c < 1.0f ? c : 1.0f) : 0.0f; };
@@ -1151,6 +1189,9 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             c->ws.parity ^= 1u;
             EventPair ev{};
             if (dev->profiling) { mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r; }
+            // ordered segment: slots of primitives that no draw of the segment covers (a Never draw keeps its ids) must read
+            // as "no coverage" -- an all-zero record is a degenerate triangle whose edge functions are negative everywhere
+            if (P.ordered_recs && P.ordered_count) HIP_TRY(hipMemsetAsync(P.ordered_recs, 0, (size_t)P.ordered_count * sizeof(TriRec), stream));
             HIP_TRY(launch_vertex(P, dp, stream));
             HIP_TRY(launch_geometry(P, dp, stream));
             if (dev->profiling) {

@@ -25,6 +25,8 @@ constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t MAX_PRIM_ID = 0xFFFFFFFDu;
 
 enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u };
+constexpr uint32_t ORDERED_MARKER = 0xFFFFFFFFu;   // bbox-y word of an ordered slot whose triangle was clipped: pieces live in the big list
+constexpr int ORDERED_THREADS = 256;
 
 struct DrawDesc {
     const uint8_t* vb;            // binding 0 base + bind offset
@@ -118,6 +120,11 @@ struct PassParams {
     uint32_t tp_max_area;             // records whose pixel box inside the tile has at most this many pixels are resolved
                                       // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
+    // ordered segments (blending; any depth state whose result depends on the order of all fragments): the geometry kernel
+    // writes triangle t of the segment to ordered_recs[t] instead of binning it, the ordered kernel walks that array
+    TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;
+    uint32_t ord_depth_test, ord_depth_write, ord_depth_op;
+    uint32_t blend[8];                // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
     uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
 };
 

@@ -161,10 +161,37 @@ __device__ __forceinline__ void clip_and_emit(ParamsRef P, DrawRef D, f4 (*poly)
         n = m;
         f4* s = in; in = tmp; tmp = s;
     }
+    if (!P.ordered_recs) {
+        for (int i = 1; i + 1 < n; i++) {
+            const f4 tri[3] = {in[0], in[i], in[i + 1]};
+            ScreenTri t;
+            if (setup_triangle(P, D, tri, prim, t)) emit_big(P, t);
+        }
+        return;
+    }
+    // ordered segment: the pieces must stay together at the triangle's position in primitive order.  They go to one
+    // contiguous range of the big list (counted first, reserved with one atomic) and the triangle's ordered slot becomes a
+    // marker {first piece, piece count}.
+    uint32_t pieces = 0;
     for (int i = 1; i + 1 < n; i++) {
         const f4 tri[3] = {in[0], in[i], in[i + 1]};
         ScreenTri t;
-        if (setup_triangle(P, D, tri, prim, t)) emit_big(P, t);
+        if (setup_triangle(P, D, tri, prim, t)) pieces++;
+    }
+    uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
+    uint32_t first = 0;
+    if (pieces) {
+        first = atomicAdd(P.big_count, pieces);
+        if (first + pieces > P.big_cap) { __hip_atomic_fetch_or(P.status, STATUS_BIG_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); pieces = 0; }
+    }
+    slot[0] = make_uint4(first, pieces, 0u, 0u);
+    slot[1] = make_uint4(0u, 0u, 0u, 0u);
+    slot[2] = make_uint4(0u, 0u, 1u, pieces ? ORDERED_MARKER : 0u);          // (bbox x = {min 1, max 0}: empty unless marked)
+    uint32_t k = 0;
+    for (int i = 1; i + 1 < n && pieces; i++) {
+        const f4 tri[3] = {in[0], in[i], in[i + 1]};
+        ScreenTri t;
+        if (setup_triangle(P, D, tri, prim, t)) store_tri(reinterpret_cast<uint4*>(P.big_recs) + (size_t)(first + k++) * 3u, t);
     }
 }
 
@@ -408,6 +435,17 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
         P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
     }
     GSTAMP(1);
+    if (P.ordered_recs) {
+        // ordered segment: no bins -- triangle t of the segment sits at ordered_recs[t], in primitive order by construction
+        if (tri < D.tri_count && !dropped && any == 0) {
+            uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
+            if (valid) store_tri(slot, t);
+            else { slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u); }   // empty pixel box
+        } else if (tri < D.tri_count && dropped) {
+            uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
+            slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u);
+        }
+    } else
     bin_triangle_pairs(P, valid, t, lds_tri, lds_meta, lds_owner);
     GSTAMP(2);
     uint64_t todo = __ballot(any != 0);

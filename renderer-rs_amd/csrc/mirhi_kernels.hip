@@ -30,6 +30,7 @@ namespace mirhi {
 #include "mirhi_geometry.hip.h"
 #include "mirhi_shading.hip.h"
 #include "mirhi_raster.hip.h"
+#include "mirhi_ordered.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
@@ -64,6 +65,15 @@ static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t p
 hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
+    if (P.ordered_recs) {           // ordered segment: fragments in primitive order (blending)
+        const RasterHead HO = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap};
+        const dim3 og(P.tiles_x, rows), ob(ORDERED_THREADS);
+        if (programs == 2) hipLaunchKernelGGL(ordered_kernel<2>, og, ob, 0, stream, dev_params, HO);
+        else if (programs == 3) hipLaunchKernelGGL(ordered_kernel<3>, og, ob, 0, stream, dev_params, HO);
+        else if (programs >= 4) hipLaunchKernelGGL(ordered_kernel<4>, og, ob, 0, stream, dev_params, HO);
+        else hipLaunchKernelGGL(ordered_kernel<1>, og, ob, 0, stream, dev_params, HO);
+        return hipGetLastError();
+    }
     const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;

@@ -283,6 +283,19 @@ enum class PolygonMode { Fill = 0, Line, Point };
 enum class CullMode { None = 0, Front, Back, FrontAndBack };
 enum class FrontFace { CounterClockwise = 0, Clockwise };
 enum class CompareOp { Never = 0, Less, Equal, LessOrEqual, Greater, NotEqual, GreaterOrEqual, Always };
+enum class BlendFactor { Zero = 0, One, SrcColor, OneMinusSrcColor, DstColor, OneMinusDstColor, SrcAlpha, OneMinusSrcAlpha, DstAlpha, OneMinusDstAlpha,
+                         ConstantColor, OneMinusConstantColor, ConstantAlpha, OneMinusConstantAlpha, SrcAlphaSaturate };   // pipeline.rs:411-448
+enum class BlendOp { Add = 0, Subtract, ReverseSubtract, Min, Max };                                                           // pipeline.rs:452-476
+struct ColorBlendAttachment {   // pipeline.rs:478-531
+    bool blend_enable = false;
+    BlendFactor src_color_blend_factor = BlendFactor::One, dst_color_blend_factor = BlendFactor::Zero; BlendOp color_blend_op = BlendOp::Add;
+    BlendFactor src_alpha_blend_factor = BlendFactor::One, dst_alpha_blend_factor = BlendFactor::Zero; BlendOp alpha_blend_op = BlendOp::Add;
+    uint32_t color_write_mask = 0xF;
+    static ColorBlendAttachment alpha_blend() {      // :518-529  src * src_alpha + dst * (1 - src_alpha)
+        ColorBlendAttachment a; a.blend_enable = true; a.src_color_blend_factor = BlendFactor::SrcAlpha; a.dst_color_blend_factor = BlendFactor::OneMinusSrcAlpha;
+        return a;
+    }
+};
 
 class Pipeline {
 public:
@@ -314,6 +327,13 @@ public:
     GraphicsPipelineBuilder& depth_test_enable(bool e) { d_.depth_test_enable = e; return *this; }
     GraphicsPipelineBuilder& depth_write_enable(bool e) { d_.depth_write_enable = e; return *this; }
     GraphicsPipelineBuilder& depth_compare_op(CompareOp op) { d_.depth_compare_op = (int32_t)op; return *this; }
+    GraphicsPipelineBuilder& color_blend_attachment(const ColorBlendAttachment& a) {      // pipeline.rs color_blend_attachments
+        d_.blend_enable = a.blend_enable ? 1u : 0u;
+        d_.src_color_blend_factor = (int32_t)a.src_color_blend_factor; d_.dst_color_blend_factor = (int32_t)a.dst_color_blend_factor; d_.color_blend_op = (int32_t)a.color_blend_op;
+        d_.src_alpha_blend_factor = (int32_t)a.src_alpha_blend_factor; d_.dst_alpha_blend_factor = (int32_t)a.dst_alpha_blend_factor; d_.alpha_blend_op = (int32_t)a.alpha_blend_op;
+        d_.color_write_mask = a.color_write_mask;
+        return *this;
+    }
     GraphicsPipelineBuilder& color_attachment_format(Format f) { d_.color_attachment_formats[d_.color_attachment_count++ & 3] = (int32_t)f; return *this; }
     GraphicsPipelineBuilder& depth_attachment_format(Format f) { d_.depth_attachment_format = (int32_t)f; return *this; }
     const mirhi_pipeline_desc& desc() const { return d_; }

@@ -65,6 +65,10 @@ static void cpu_tests() {
     GraphicsPipelineBuilder b;
     CHECK(b.desc().topology == MIRHI_TOPOLOGY_TRIANGLE_LIST && b.desc().cull_mode == MIRHI_CULL_BACK && b.desc().front_face == MIRHI_FRONT_FACE_COUNTER_CLOCKWISE);
     CHECK(b.desc().depth_test_enable == 1 && b.desc().depth_write_enable == 1 && b.desc().depth_compare_op == MIRHI_COMPARE_LESS);
+    CHECK(b.desc().blend_enable == 0 && b.desc().src_color_blend_factor == MIRHI_BLEND_ONE && b.desc().dst_color_blend_factor == MIRHI_BLEND_ZERO && b.desc().color_write_mask == 0xF);
+    GraphicsPipelineBuilder ab; ab.color_blend_attachment(ColorBlendAttachment::alpha_blend());      // pipeline.rs:518-529
+    CHECK(ab.desc().blend_enable == 1 && ab.desc().src_color_blend_factor == MIRHI_BLEND_SRC_ALPHA && ab.desc().dst_color_blend_factor == MIRHI_BLEND_ONE_MINUS_SRC_ALPHA &&
+          ab.desc().src_alpha_blend_factor == MIRHI_BLEND_ONE && ab.desc().dst_alpha_blend_factor == MIRHI_BLEND_ZERO && ab.desc().alpha_blend_op == MIRHI_BLEND_OP_ADD);
     mirhi_rendering_info ri; mirhi_rendering_info_default(&ri);
     CHECK(ri.color_load_op == MIRHI_LOAD_OP_CLEAR && ri.color_store_op == MIRHI_STORE_OP_STORE && ri.clear_color[3] == 1.0f && ri.clear_color[0] == 0.0f);
     CHECK(ri.depth_load_op == MIRHI_LOAD_OP_CLEAR && ri.depth_store_op == MIRHI_STORE_OP_DONT_CARE && ri.clear_depth == 1.0f);

@@ -19,6 +19,13 @@ PROGRAM_TRIANGLE, PROGRAM_MODEL, PROGRAM_MODEL_FULL, PROGRAM_MODEL_PBR = 0, 1, 2
 CULL_NONE, CULL_FRONT, CULL_BACK, CULL_FRONT_AND_BACK = 0, 1, 2, 3
 FRONT_CCW, FRONT_CW = 0, 1
 CMP_NEVER, CMP_LESS, CMP_EQUAL, CMP_LESS_OR_EQUAL, CMP_GREATER, CMP_NOT_EQUAL, CMP_GREATER_OR_EQUAL, CMP_ALWAYS = range(8)
+# crates/rhi/src/pipeline.rs:411-448 BlendFactor, :452-476 BlendOp (reference enum order)
+(BF_ZERO, BF_ONE, BF_SRC_COLOR, BF_ONE_MINUS_SRC_COLOR, BF_DST_COLOR, BF_ONE_MINUS_DST_COLOR, BF_SRC_ALPHA, BF_ONE_MINUS_SRC_ALPHA,
+ BF_DST_ALPHA, BF_ONE_MINUS_DST_ALPHA, BF_CONSTANT_COLOR, BF_ONE_MINUS_CONSTANT_COLOR, BF_CONSTANT_ALPHA, BF_ONE_MINUS_CONSTANT_ALPHA,
+ BF_SRC_ALPHA_SATURATE) = range(15)
+BO_ADD, BO_SUBTRACT, BO_REVERSE_SUBTRACT, BO_MIN, BO_MAX = range(5)
+# ColorBlendAttachment::alpha_blend() (pipeline.rs:518-529): (src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask)
+ALPHA_BLEND = (BF_SRC_ALPHA, BF_ONE_MINUS_SRC_ALPHA, BO_ADD, BF_ONE, BF_ZERO, BO_ADD, 0xF)
 
 f32 = np.float32
 
@@ -238,6 +245,7 @@ class DrawSpec:
     metallic_roughness_map: Optional[Texture] = None   # MODEL_PBR only (model_pbr.hlsl:62-95 t2..t4)
     occlusion_map: Optional[Texture] = None
     emissive_map: Optional[Texture] = None
+    blend: Optional[tuple] = None         # None = opaque; else (src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask)
 
     @property
     def textures(self):

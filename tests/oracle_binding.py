@@ -31,6 +31,8 @@ class OracleDraw(C.Structure):
         ("point_lights", C.c_void_p), ("spot_lights", C.c_void_p),
         ("albedo_map", OracleTexture), ("normal_map", OracleTexture),
         ("metallic_roughness_map", OracleTexture), ("occlusion_map", OracleTexture), ("emissive_map", OracleTexture),
+        ("blend_enable", C.c_uint32), ("src_color_factor", C.c_uint32), ("dst_color_factor", C.c_uint32), ("color_op", C.c_uint32),
+        ("src_alpha_factor", C.c_uint32), ("dst_alpha_factor", C.c_uint32), ("alpha_op", C.c_uint32), ("color_write_mask", C.c_uint32),
     ]
 
 
@@ -106,6 +108,10 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
         od.count, od.first, od.vertex_offset = d.count, d.first, d.vertex_offset
         od.program, od.cull_mode, od.front_face = d.program, d.cull_mode, d.front_face
         od.depth_test, od.depth_write, od.depth_compare = int(d.depth_test), int(d.depth_write), d.depth_compare
+        if getattr(d, "blend", None) is not None:
+            od.blend_enable = 1
+            (od.src_color_factor, od.dst_color_factor, od.color_op, od.src_alpha_factor, od.dst_alpha_factor, od.alpha_op,
+             od.color_write_mask) = d.blend
         vp = d.viewport or (0.0, 0.0, float(scene.width), float(scene.height), 0.0, 1.0)
         sc = d.scissor or (0, 0, scene.width, scene.height)
         od.viewport = (C.c_float * 6)(*vp)

@@ -195,17 +195,28 @@ def test_fuzz_predicate_depth_states(mirhi, oracle, device, scenes, seed):
     assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32)), f"{scene.name} op {op} write {write}: depth differs"
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_fuzz_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, seed):
-    """Every draw of the scope gets its own depth state (any compare op, test on/off, write on/off; NotEqual only without
-    write): the scope is cut into segments at each change (DESIGN.md "Depth key") and must still equal the oracle's
-    fragment-by-fragment order."""
-    scene = _random_scene(scenes, 9000 + seed)
-    rng = np.random.default_rng(9500 + seed)
+def _randomize_states(scenes, scene, rng):
+    """Per-draw depth state (any compare op, test / write on or off) and, for a third of the draws, a random
+    ColorBlendAttachment (every factor the pipeline accepts, every op, random write mask)."""
+    factors = [f for f in range(15) if not (scenes.BF_CONSTANT_COLOR <= f <= scenes.BF_ONE_MINUS_CONSTANT_ALPHA)]
     for d in scene.draws:
         d.depth_test = bool(rng.random() < 0.8)
         d.depth_compare = int(rng.integers(0, 8))
-        d.depth_write = bool(rng.random() < 0.6) and d.depth_compare != scenes.CMP_NOT_EQUAL
+        d.depth_write = bool(rng.random() < 0.6)
+        if rng.random() < 0.35:
+            d.blend = (int(rng.choice(factors)), int(rng.choice(factors)), int(rng.integers(0, 5)), int(rng.choice(factors)),
+                       int(rng.choice(factors)), int(rng.integers(0, 5)), int(rng.integers(1, 16)))
+    scene.clear_color = tuple(float(x) for x in rng.uniform(0, 1, 4))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, seed):
+    """Every draw of the scope gets its own depth state and maybe a blend state: the scope is cut into segments at each
+    change, blended / order-dependent ones go through the ordered kernel (DESIGN.md "Depth key", "Ordered segments"), and
+    the result must still equal the oracle's fragment-by-fragment order."""
+    scene = _random_scene(scenes, 9000 + seed)
+    rng = np.random.default_rng(9500 + seed)
+    _randomize_states(scenes, scene, rng)
     scene.clear_depth = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
     res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
     res.render()
@@ -217,5 +228,6 @@ def test_fuzz_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, see
     a, b = out["color"], ref["rgba"]
     nan = np.isnan(b)
     assert np.array_equal(np.isnan(a), nan)
-    err = np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b)))
+    with np.errstate(invalid="ignore"):      # equal infinities (feedback blend factors overflow on both sides alike) are no error
+        err = np.where(a == b, 0.0, np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b))))
     assert err.max() < 1e-4

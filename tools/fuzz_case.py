@@ -9,17 +9,15 @@ import oracle_binding as ob
 spec = importlib.util.spec_from_file_location("fz", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
 fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
 kind, seed = sys.argv[1], int(sys.argv[2])
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 500000      # the soak run's first seed (decides which cases get extra states)
 scene = (fz._random_scene if kind == "state" else fz._random_pbr_scene)(m.scenes, seed)
-if kind == "state" and (seed - 500000) % 3 == 0:
+if kind == "state" and (seed - first) % 3 == 0:
     rng = np.random.default_rng(seed)
     op, write = [(o, False) for o in range(8)][int(rng.integers(0, 8))]
     for d in scene.draws: d.depth_test, d.depth_write, d.depth_compare = True, write, op
-if kind == "state" and (seed - 500000) % 3 == 1:
+if kind == "state" and (seed - first) % 3 == 1:
     rng = np.random.default_rng(seed)
-    for d in scene.draws:
-        d.depth_test = bool(rng.random() < 0.8)
-        d.depth_compare = int(rng.integers(0, 8))
-        d.depth_write = bool(rng.random() < 0.6) and d.depth_compare != m.scenes.CMP_NOT_EQUAL
+    fz._randomize_states(m.scenes, scene, rng)
 dev = m.Device(0)
 res = m.SceneResources(dev, scene, want_prim=True, want_depth=True)
 res.render(); out = res.read(); res.destroy()
@@ -39,3 +37,9 @@ if d.material is not None:
     print("material floats", mat[:12], "flags", np.frombuffer(d.material, dtype=np.int32)[12:17] if len(d.material) >= 68 else None)
 print("pixels above 1e-4:", int((err.max(axis=2) > 1e-4).sum()), "of covered", int((ref["prim"] != 0xFFFFFFFF).sum()))
 dev.destroy()
+nan_a, nan_b = np.isnan(a).any(axis=2), np.isnan(b).any(axis=2)
+if (nan_a != nan_b).any():
+    ys, xs = np.nonzero(nan_a != nan_b)
+    print("NaN pattern differs at", len(ys), "pixels; first", (xs[0], ys[0]), "gpu", a[ys[0], xs[0]], "oracle", b[ys[0], xs[0]], "prim", ref["prim"][ys[0], xs[0]])
+    for di, d in enumerate(scene.draws): print(" draw", di, "program", d.program, "tris", d.num_triangles, "depth", d.depth_test, d.depth_write, d.depth_compare, "blend", d.blend)
+    print(" clear", scene.clear_color)
