@@ -97,3 +97,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_binding" not in text and "libmirhi_oracle" not in text and "mirhi_oracle.h" not in text, f
+
+
+def test_generated_rust_sys_crate_covers_the_header():
+    """bindings/rust/mirhi-sys/src/lib.rs (tools/gen_rust_sys.py; no Rust toolchain here, so it is generated, not compiled):
+    up to date with the header, one `pub fn` per C function with the same number of parameters, every struct and enum."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(root, "tools", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, funcs = gen.generate()
+    assert open(gen.OUT).read() == text, "stale: run tools/gen_rust_sys.py"
+    opaque, enums, structs, parsed = gen.parse(open(gen.HEADER).read())
+    assert len(parsed) >= 60 and {"mirhi_pipeline_desc", "mirhi_rendering_info", "mirhi_viewport", "mirhi_rect2d"} <= set(structs)
+    for name, ret, params in parsed:
+        m = re.search(r"pub fn " + name + r"\((.*?)\)( -> [^;]+)?;", text)
+        assert m, name
+        assert (len([p for p in m.group(1).split(",") if p.strip()]) == len(params)), name
+    for e, items in enums.items():
+        for k, v in items:
+            assert f"pub const {k}: {e} = {v};" in text
+    assert "pub const MIRHI_ERR_PIPELINE: mirhi_result = 9;" in text
