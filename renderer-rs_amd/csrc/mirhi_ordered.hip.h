@@ -134,21 +134,30 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
     const uint32_t nbig_raw = *H.big_count;
     if (tid == 0 && tile == 0) { *P.big_count_next = 0; P.status[1] = nbig_raw; }   // (bins are not used by an ordered segment)
 
+    // The pixel state is set up when the first record of the segment reaches this tile.  A tile no record reaches has nothing
+    // to do at all if the segment keeps the colour (and depth) written so far -- the usual case for translucent geometry over
+    // an opaque frame -- so it neither reads nor rewrites its 4 KB of the target.
+    const bool may_skip = P.color_load && !(P.depth && P.depth_store && !P.depth_load);
+    bool loaded = false;
+    auto load_state = [&]() {
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
-        const bool inb = px < P.width && py < P.height;
-        const size_t pix = (size_t)py * P.width + px;
-        f4 c0 = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
-        if (P.color_load && inb) {
-            if (P.color_format == 2) { const float4 c = reinterpret_cast<const float4*>(P.color)[pix]; c0 = {c.x, c.y, c.z, c.w}; }
-            else c0 = unpack_bgra8_srgb(reinterpret_cast<const uint32_t*>(P.color)[pix]);
+        for (int b = 0; b < 4; b++) {
+            const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
+            const bool inb = px < P.width && py < P.height;
+            const size_t pix = (size_t)py * P.width + px;
+            f4 c0 = {P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]};
+            if (P.color_load && inb) {
+                if (P.color_format == 2) { const float4 c = reinterpret_cast<const float4*>(P.color)[pix]; c0 = {c.x, c.y, c.z, c.w}; }
+                else c0 = unpack_bgra8_srgb(reinterpret_cast<const uint32_t*>(P.color)[pix]);
+            }
+            ORD_STATE(0u, b) = (P.depth_load && P.depth && inb) ? __float_as_uint(P.depth[pix]) : P.clear_depth_bits;
+            ORD_STATE(1u, b) = NO_PRIM;
+            ORD_STATE(2u, b) = __float_as_uint(c0.x); ORD_STATE(3u, b) = __float_as_uint(c0.y);
+            ORD_STATE(4u, b) = __float_as_uint(c0.z); ORD_STATE(5u, b) = __float_as_uint(c0.w);
         }
-        ORD_STATE(0u, b) = (P.depth_load && P.depth && inb) ? __float_as_uint(P.depth[pix]) : P.clear_depth_bits;
-        ORD_STATE(1u, b) = NO_PRIM;
-        ORD_STATE(2u, b) = __float_as_uint(c0.x); ORD_STATE(3u, b) = __float_as_uint(c0.y);
-        ORD_STATE(4u, b) = __float_as_uint(c0.z); ORD_STATE(5u, b) = __float_as_uint(c0.w);
-    }
+        loaded = true;
+    };
+    if (!may_skip) load_state();
     const uint4* slots = reinterpret_cast<const uint4*>(P.ordered_recs);
     const uint4* pieces = reinterpret_cast<const uint4*>(P.big_recs);
     for (uint32_t base = 0; base < P.ordered_count; base += ORDERED_THREADS) {
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
                 lds_box[slot] = box;
             }
             __syncthreads();
+            if (n && !loaded) load_state();
             for (uint32_t j = 0; j < n; j++) {
                 const uint32_t mj = lds_rec[j * 4u + 3u].w;
                 if (mj & qmask) ordered_record<PROGS>(load_rec(lds_rec, j), lds_box[j], ix0, iy0, fix0, fiy0, px0, py0, P, lds_state, tid, qbit0);
@@ -221,6 +231,7 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
                 }
                 __syncthreads();
                 const uint32_t pn = lds_wave[0];
+                if (pn && !loaded) load_state();
                 for (uint32_t j = 0; j < pn; j++) {
                     const uint32_t mj = lds_rec[j * 4u + 3u].w;
                     if (mj & qmask) ordered_record<PROGS>(load_rec(lds_rec, j), lds_box[j], ix0, iy0, fix0, fiy0, px0, py0, P, lds_state, tid, qbit0);
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
         }
     }
     // ---- store ----
+    if (!loaded) return;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
