@@ -146,6 +146,7 @@ struct Workspace {
     PassParams* params = nullptr; size_t params_bytes = 0;   // two copies per scope (big-list counter parity 0 / 1), read by the kernels
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
+    uint32_t* prim_draw = nullptr; size_t prim_draw_bytes = 0;     // per primitive: its draw (scopes with several draws)
     uint32_t* status_host = nullptr;                             // pinned, device-mapped: [status bits, big-list length]
     uint32_t* status_dev = nullptr;                              // device view of status_host
     uint32_t* big_counts = nullptr;                              // two counters, used alternately (parity)
@@ -619,6 +620,7 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.ordered) (void)hipFree(w.ordered);
     if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.flat_color) (void)hipFree(w.flat_color);
+    if (w.prim_draw) (void)hipFree(w.prim_draw);
     if (w.status_host) (void)hipHostFree(w.status_host);
     w = Workspace();
 }
@@ -1054,6 +1056,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         if (tri_prog && pass.info.color_image->format == MIRHI_FORMAT_B8G8R8A8_SRGB && pass.total_tris > flat_tris) flat_tris = pass.total_tris;
     }
     if (flat_tris && (r = grow(&w.flat_color, &w.flat_color_bytes, flat_tris * 4)) != MIRHI_OK) return r;
+    {
+        size_t pd = 0;
+        for (auto& pass : cmd->passes)
+            if (pass.draws.size() > 1 && (size_t)(pass.total_tris - pass.first_tri) > pd) pd = pass.total_tris - pass.first_tri;
+        if (pd && (r = grow(&w.prim_draw, &w.prim_draw_bytes, pd * 4)) != MIRHI_OK) return r;
+    }
 
     // upload draw descriptors, build per-pass parameters
     std::vector<DrawDesc> all;
@@ -1099,6 +1107,8 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
+        P.first_prim = pass.first_tri;
+        P.prim_draw = pass.draws.size() > 1 ? w.prim_draw : nullptr;
         {
             bool tri_prog = false;
             for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;

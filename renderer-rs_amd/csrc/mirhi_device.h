@@ -115,6 +115,8 @@ struct PassParams {
     TileRec*  bin_recs; uint32_t* bin_count; uint32_t bin_cap;
     BigRec*   big_recs; uint32_t* big_count; uint32_t big_cap;
     uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
+    uint32_t* prim_draw;              // per primitive of the scope (index prim - first_prim): its draw, written by the geometry kernel when
+    uint32_t  first_prim;             // the scope has several draws -- one load in the resolve instead of a binary search per pixel
     uint32_t* flat_color;             // per primitive: B8G8R8A8_SRGB colour if its three vertex colours are equal (TRIANGLE
                                       // program, sRGB8 target), else 0; lets the resolve skip interpolation + OETF
     uint32_t tp_max_area;             // records whose pixel box inside the tile has at most this many pixels are resolved

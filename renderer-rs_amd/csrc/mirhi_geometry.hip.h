@@ -196,6 +196,7 @@ __device__ __forceinline__ void clip_and_emit(ParamsRef P, DrawRef D, f4 (*poly)
 }
 
 __device__ __forceinline__ uint32_t find_draw(ParamsRef P, uint32_t prim) {
+    if (P.prim_draw) return P.prim_draw[prim - P.first_prim];
     uint32_t lo = 0, hi = P.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             if (any == 0 && in_band) valid = setup_triangle(P, D, c, prim, t);
         }
     }
+    if (P.prim_draw && tri < D.tri_count) P.prim_draw[prim - P.first_prim] = lo;      // (several draws in the scope)
     if (P.flat_color && D.program == 0 && (valid || any)) {
         // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
         const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
