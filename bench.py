@@ -224,6 +224,7 @@ def main():
     torch.cuda.synchronize()
     geo_ms, geo_n = dev.kernel_time(m.Kernel.GEOMETRY)
     ras_ms, ras_n = dev.kernel_time(m.Kernel.RASTER)
+    ov_ms, ov_n = dev.event_overhead()       # already subtracted per launch from the two figures above
     dev.set_profiling(False)
 
     split_extra = None
@@ -261,7 +262,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if split else measured_traffic(args.workload),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": round(ras_us, 3),
                          "geometry_kernel_us": round(geo_us, 3),
-                         "how": "hipEvent pairs on the submit stream around every launch; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
+                         "event_pair_overhead_us": round(1e3 * ov_ms, 3), "event_pair_samples": ov_n,
+                         "how": "hipEvent pairs on the submit stream around every launch, minus the mean of one EMPTY pair recorded behind each frame's raster pair; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
             "workspace_mb": round(stats.workspace_bytes / 1e6, 1), "big_list": stats.last_big_list,
         }
         if split_extra is not None:

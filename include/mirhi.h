@@ -244,10 +244,13 @@ mirhi_result mirhi_fence_destroy(mirhi_fence* fence);
 /* ---- measurement: per-kernel device time from HIP events on the submit stream ---------- */
 typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_COUNT = 2 } mirhi_kernel_id;
 mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);   /* brackets each kernel with hipEvents */
-/* accumulated since the last reset; waits for outstanding events.  The duration of an empty event pair on the stream
- * (calibrated when profiling is enabled, ~4.6 us on MI355X) is subtracted per launch, so the figure matches the
- * kernel duration rocprofv3 --kernel-trace reports. */
+/* accumulated since the last reset; waits for outstanding events.  An event pair costs stream time even around nothing
+ * (~4.6 us on MI355X); every profiled scope therefore also records one EMPTY pair behind its raster pair, and the mean of
+ * those in-situ samples is subtracted per launch (before any scope has run: a one-off calibration taken when profiling
+ * is enabled), so the figure is the kernel's own duration as rocprofv3 --kernel-trace sees it. */
 mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches);
+/* the per-launch correction mirhi_device_kernel_time applies, and the number of in-situ samples behind it (0 = calibration) */
+mirhi_result mirhi_device_event_overhead(mirhi_device* dev, double* overhead_ms, uint64_t* samples);
 mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev);
 typedef struct {
     uint64_t frames_submitted;      /* rendering scopes executed */

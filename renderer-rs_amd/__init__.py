@@ -213,6 +213,7 @@ _SIGNATURES = {
     "mirhi_device_set_profiling": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_kernel_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mirhi_device_reset_kernel_times": (C.c_int32, [C.c_void_p]),
+    "mirhi_device_event_overhead": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mirhi_device_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(DeviceStats)]),
 }
 
@@ -288,6 +289,12 @@ class Device:
     def kernel_time(self, kernel: int):
         ms, n = C.c_double(), C.c_uint64()
         check(lib().mirhi_device_kernel_time(self.handle, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def event_overhead(self):
+        """(milliseconds subtracted per launch by kernel_time, in-situ samples behind it)"""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(lib().mirhi_device_event_overhead(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def reset_kernel_times(self):

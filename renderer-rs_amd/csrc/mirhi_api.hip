@@ -90,8 +90,11 @@ struct mirhi_device {
     bool profiling = false;
     std::mutex mu;
     std::vector<EventPair> pending[MIRHI_KERNEL_COUNT];
+    std::vector<EventPair> pending_empty;     // one EMPTY pair per profiled scope, recorded right behind the raster pair
     std::vector<EventPair> free_events;
     double event_overhead_ms = 0.0;          // calibrated duration of an EMPTY hipEvent pair on the submit stream
+    double empty_ms = 0.0;                   // in-situ empty pairs since the last reset: same stream, same clocks, same
+    uint64_t empty_n = 0;                    //   queue state as the kernel pairs they correct
     double total_ms[MIRHI_KERNEL_COUNT] = {0, 0};
     uint64_t launches[MIRHI_KERNEL_COUNT] = {0, 0};
     mirhi_device_stats stats{};
@@ -276,6 +279,7 @@ extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
     (void)sync_all_lanes(dev);
     for (size_t i = 1; i < dev->lanes.size(); i++) (void)hipStreamDestroy(dev->lanes[i]);
     for (auto& v : dev->pending) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : dev->pending_empty) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : dev->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (dev->owns_stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
@@ -1210,7 +1214,11 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
                 mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r;
             }
             HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream));
-            if (dev->profiling) { HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev); }
+            if (dev->profiling) {
+                HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev);
+                mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r;
+                HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending_empty.push_back(ev);
+            }
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += P.total_tris;
         }
@@ -1351,7 +1359,20 @@ static mirhi_result drain_events(mirhi_device* dev) {
         }
         dev->pending[k].clear();
     }
+    for (auto& p : dev->pending_empty) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        dev->empty_ms += ms; dev->empty_n++;
+        dev->free_events.push_back(p);
+    }
+    dev->pending_empty.clear();
     return MIRHI_OK;
+}
+// Stream time of an event pair around nothing: the in-situ samples of this measurement window when there are any (they saw
+// the same clocks and queue state as the kernel pairs), else the one-off calibration of mirhi_device_set_profiling.
+static double event_overhead(const mirhi_device* dev) {
+    return dev->empty_n ? dev->empty_ms / (double)dev->empty_n : dev->event_overhead_ms;
 }
 extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches) {
     NULL_CHECK(dev, "device");
@@ -1360,10 +1381,19 @@ extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
     if (total_ms) {
-        const double corrected = dev->total_ms[kernel] - dev->event_overhead_ms * (double)dev->launches[kernel];
+        const double corrected = dev->total_ms[kernel] - event_overhead(dev) * (double)dev->launches[kernel];
         *total_ms = corrected > 0.0 ? corrected : 0.0;
     }
     if (launches) *launches = dev->launches[kernel];
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_event_overhead(mirhi_device* dev, double* overhead_ms, uint64_t* samples) {
+    NULL_CHECK(dev, "device");
+    std::lock_guard<std::mutex> lock(dev->mu);
+    mirhi_result r = drain_events(dev);
+    if (r != MIRHI_OK) return r;
+    if (overhead_ms) *overhead_ms = event_overhead(dev);
+    if (samples) *samples = dev->empty_n;
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
@@ -1372,6 +1402,7 @@ extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
     for (int k = 0; k < MIRHI_KERNEL_COUNT; k++) { dev->total_ms[k] = 0; dev->launches[k] = 0; }
+    dev->empty_ms = 0.0; dev->empty_n = 0;
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out) {

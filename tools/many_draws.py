@@ -39,3 +39,14 @@ for program in (S.PROGRAM_TRIANGLE, S.PROGRAM_MODEL):
         print(f"program {program} {name:12s} ({nd * per} tris): record+build {1e3 * t_rec:7.1f} ms  geometry {1e3 * g_ / max(gn, 1):8.2f} us  raster {1e3 * r_ / max(rn, 1):8.2f} us")
         res.destroy()
 dev.destroy()
+
+# per-frame cost of re-recording a command buffer with many draws (resources already exist)
+dev = m.Device(0)
+base = S.random_triangles(nd * per, 1920, 1080, seed=5, rmin=2, rmax=12).draws[0].vertices.reshape(-1, 6)
+many = [S.DrawSpec(vertices=base[i * per * 3:(i + 1) * per * 3].copy(), stride=24, count=per * 3, cull_mode=S.CULL_NONE) for i in range(nd)]
+res = m.SceneResources(dev, S.Scene("many", 1920, 1080, many), m.Format.B8G8R8A8_SRGB)
+t0 = time.perf_counter()
+for _ in range(5): res.record()
+dt = (time.perf_counter() - t0) / 5
+print(f"re-recording {nd} draws: {1e3 * dt:.2f} ms per command buffer ({1e6 * dt / nd:.2f} us per draw incl. the Python binding)")
+res.destroy(); dev.destroy()
