@@ -967,6 +967,15 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         band_tile_rows(dev, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
         size_t cap = tiles ? (8ull * pass.total_tris) / tiles + 64 : 64;
+        {   // A mesh concentrates its triangles in the tiles it covers (the dancer asset: 17k triangles in 232 of 2040 tiles,
+            // 919 in the fullest), so the average says little: give every tile room for 1024 records (or all of them, if
+            // the scope has fewer) before it has to overflow into the big list, which EVERY tile walks.  Costs address
+            // space only (48 B x cap x tiles: 100 MB at 1080p, 400 MB at 4K); measured: dancer raster 134 -> 97 us, C3
+            // 41.6 -> 37.3 us, C2 / C5 unchanged.  MIRHI_BIN_CAP_FLOOR overrides for A/B runs.
+            size_t floor_cap = getenv("MIRHI_BIN_CAP_FLOOR") ? (size_t)atoi(getenv("MIRHI_BIN_CAP_FLOOR")) : 1024;
+            if (floor_cap > pass.total_tris) floor_cap = pass.total_tris;
+            if (cap < floor_cap) cap = floor_cap;
+        }
         cap = (cap + 63) & ~(size_t)63;
         if (cap > 4096) cap = 4096;
         g.bin_cap = (uint32_t)cap;
@@ -1119,10 +1128,18 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
         {   // triangle-parallel resolve of small records pays when tiles hold many triangles (meshes); sparse scopes keep
-            // the leaner pixel-parallel-only kernel.  MIRHI_TP_MAX_AREA overrides (0 = off) for A/B measurements.
+            // the leaner pixel-parallel-only kernel.  Scopes of TRIANGLE-program draws switch at 16 triangles per tile on
+            // average (their variant gives up one wave of occupancy for the LDS key array); mesh-program scopes lose nothing
+            // and a mesh covers a fraction of the frame (the dancer asset: 8 per tile on average, 124 per tile it touches),
+            // so they switch at 4.  Box limit 64 pixels: measured against 96 / 128 on the dancer (74 / 81 / 89 us), C3
+            // (38.6 / 36.8 / 37.1), C4 (112.9 / 112.4 / 112.4) and C5 (202 / 206 / 211).
+            // MIRHI_TP_MAX_AREA (0 = off) and MIRHI_TP_DENSITY override for A/B measurements.
             const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-            const bool dense = tiles && (pass.total_tris - pass.first_tri) / tiles >= 16;
-            P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 128u : 0u);
+            bool tri_prog = false;
+            for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
+            const size_t density = getenv("MIRHI_TP_DENSITY") ? (size_t)atoi(getenv("MIRHI_TP_DENSITY")) : (tri_prog ? 16 : 4);
+            const bool dense = tiles && (pass.total_tris - pass.first_tri) / tiles >= density;
+            P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 64u : 0u);
             if (P.pred) P.tp_max_area = 0;    // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;

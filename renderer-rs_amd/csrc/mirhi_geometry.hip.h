@@ -249,6 +249,32 @@ __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
 // record copy per pair.  Every lane stays busy; a lane walking its own <= 16 bins (the first design) issued 2-3x the
 // instructions per wave, and sixteen lanes per triangle 10x (measured: C2 907 / 987 / 1089 Mtris/s for walk / wide / pairs).
 constexpr uint32_t PAIR_MAX = GEOM_THREADS * MAX_BIN_SPAN * MAX_BIN_SPAN;
+
+// Reserves one bin slot for every active lane with a SINGLE returning atomic instruction: lanes that target the same
+// tile (mesh order: most of a wave) are grouped first -- pure ballot arithmetic, no memory -- and only a group's first
+// lane adds, the whole group size at once; lanes left over after GROUP_ROUNDS groups, or after the first group too
+// small to be worth a round (scattered input), add 1 for themselves in the same instruction.  Returns the value the
+// lane's own add fetched (meaningful on reserving lanes) and in `who` the reserving lane | rank within its group << 8.
+// One atomic per group IN SEPARATE ROUNDS (the first design) made the compiler wait for each result before the next
+// add -- up to nine serial round trips per wave, 13 us of the dancer asset's 29 us geometry time.
+__device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uint32_t tile, uint32_t lane, uint64_t lt, uint32_t& who) {
+    constexpr int GROUP_ROUNDS = 12, GROUP_MIN = 2;
+    who = lane;
+    uint32_t gsize = act ? 1u : 0u;
+    uint64_t rem = __ballot(act);
+    for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+        const uint64_t grp = __ballot(act && tile == t0) & rem;
+        const uint32_t n = (uint32_t)__popcll(grp);
+        if (n < (uint32_t)GROUP_MIN) break;
+        if ((grp >> lane) & 1ull) { who = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8); gsize = (int)lane == leader ? n : 0u; }
+        rem &= ~grp;
+    }
+    uint32_t raw = 0;
+    if (gsize) raw = atomicAdd(&P.bin_count[tile], gsize);
+    return raw;
+}
 __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
                                                    uint32_t* lds_meta, uint16_t* lds_owner) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -266,21 +292,10 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
     if (__ballot(nb > 1u) == 0ull) {
         // Fine meshes: no triangle of the wave overlaps more than one tile.  A lane is its own pair -- no enumeration
         // through LDS, the record goes out of the registers it was built in.
-        constexpr int GROUP_ROUNDS = 8, GROUP_MIN = 2;
         const uint32_t tile = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
         const bool act = nb == 1u;
-        uint32_t raw = 0, who = lane;
-        uint64_t rem = __ballot(act);
-        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-            const uint64_t grp = __ballot(act && tile == t0) & rem;
-            if (__popcll(grp) < GROUP_MIN) break;
-            if (act && tile == t0 && ((rem >> lane) & 1ull)) who = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
-            if ((int)lane == leader) raw = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
-            rem &= ~grp;
-        }
-        if (act && ((rem >> lane) & 1ull)) raw = atomicAdd(&P.bin_count[tile], 1u);      // ungrouped lanes
+        uint32_t who;
+        const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who);
         const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
         if (act) {
             if (slot < P.bin_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
@@ -310,11 +325,9 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         }
     }
     __syncthreads();            // one wave per workgroup: orders the LDS writes above before the reads below
-    // All returning atomics of the wave are issued before the first result is consumed.  Lanes of a round that target
-    // the same tile (mesh order: most of them) are grouped and the group's first lane reserves the whole range with one
-    // atomic; grouping stops at the first small group (scattered input would only serialise its atomics).
+    // All returning atomics of the wave (one instruction per 64 pairs, reserve_bin_slots) are issued before the first
+    // result is consumed.
     constexpr uint32_t ROUNDS = PAIR_MAX / GEOM_THREADS;
-    constexpr int GROUP_ROUNDS = 8, GROUP_MIN = 2;
     uint32_t raw[ROUNDS];      // atomic result (held by the reserving lane)
     uint32_t who[ROUNDS];      // reserving lane | rank within its group << 8
 #pragma unroll
@@ -328,17 +341,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             const uint32_t o = lds_owner[p], kk = o >> 8;
             tile = lds_meta[o & 0xFFu] + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);   // (flag bit not set yet)
         }
-        uint64_t rem = __ballot(act);
-        for (int round = 0; round < GROUP_ROUNDS && rem; round++) {
-            const int leader = __ffsll((long long)rem) - 1;
-            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-            const uint64_t grp = __ballot(act && tile == t0) & rem;
-            if (__popcll(grp) < GROUP_MIN) break;
-            if (act && tile == t0 && ((rem >> lane) & 1ull)) who[it] = (uint32_t)leader | ((uint32_t)__popcll(grp & lt) << 8);
-            if ((int)lane == leader) raw[it] = atomicAdd(&P.bin_count[t0], (uint32_t)__popcll(grp));
-            rem &= ~grp;
-        }
-        if (act && ((rem >> lane) & 1ull)) raw[it] = atomicAdd(&P.bin_count[tile], 1u);   // ungrouped lanes
+        raw[it] = reserve_bin_slots(P, act, tile, lane, lt, who[it]);
     }
 #pragma unroll
     for (uint32_t it = 0; it < ROUNDS; it++) {

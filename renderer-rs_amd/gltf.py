@@ -4,7 +4,12 @@
 * POSITION is required; missing NORMAL -> +Y, TEXCOORD_0 -> (0,0), TANGENT -> (1,0,0,1); missing indices ->
   sequential 0..n (model.rs:160-215)
 * materials: base colour factor, metallic, roughness, emissive; AO 1.0 (model.rs:273-309, material.rs:6-30)
-* images are not decoded (the reference discards them, model.rs:120)
+* images: the reference lets `gltf::import` decode them and discards the result (model.rs:120); `load(path)` does
+  the same by default.  `load(path, images=True)` keeps them: every `images[i]` (file URI, data: URI or bufferView) is
+  decoded to RGBA8 by images.decode_image (PNG / baseline JPEG, host/image_decode.hpp), and each material carries the
+  image index behind its baseColor / metallicRoughness / normal / occlusion / emissive texture plus alphaMode / cutoff /
+  doubleSided -- what model_full.hlsl / model_pbr.hlsl bind at t0..t4.  An image whose file is absent (the dancer asset
+  names three and ships one) becomes None and is listed in `Model.missing_images`.
 
 This is SURVEY.md section 8f rank 1 (the caller side of the hot path): it feeds `interleave()` ->
 `Vertex` 48 B streams (crates/rhi/src/vertex.rs:88-170) that the rasterizer consumes.
@@ -34,6 +39,17 @@ class Material:   # crates/resources/src/material.rs:6-30
     roughness: float = 0.5
     ao: float = 1.0
     emissive: tuple = (0.0, 0.0, 0.0, 0.0)
+    # texture slots of model_pbr.hlsl:62-95 (t0..t4) as indices into Model.images; only filled by load(images=True)
+    base_color_image: Optional[int] = None
+    metallic_roughness_image: Optional[int] = None
+    normal_image: Optional[int] = None
+    occlusion_image: Optional[int] = None
+    emissive_image: Optional[int] = None
+    normal_scale: float = 1.0
+    occlusion_strength: float = 1.0
+    alpha_mode: str = "OPAQUE"
+    alpha_cutoff: float = 0.5
+    double_sided: bool = False
 
 
 @dataclass
@@ -64,6 +80,8 @@ class Mesh:       # crates/resources/src/model.rs:31-44
 class Model:
     meshes: List[Mesh] = field(default_factory=list)
     materials: List[Material] = field(default_factory=list)
+    images: list = field(default_factory=list)          # images.DecodedImage or None, one per glTF image (load(images=True))
+    missing_images: List[str] = field(default_factory=list)
     aabb_min: np.ndarray = None
     aabb_max: np.ndarray = None
 
@@ -97,7 +115,31 @@ def _read_accessor(doc, buffers, index) -> np.ndarray:
     return np.array(out)
 
 
-def load(path: str) -> Model:
+def _image_bytes(doc, buffers, base, img):
+    """-> (bytes or None when the file is absent, label)"""
+    if "uri" in img:
+        uri = img["uri"]
+        if uri.startswith("data:"):
+            return base64.b64decode(uri.split(",", 1)[1]), "data: URI"
+        from urllib.parse import unquote
+        full = os.path.join(base, unquote(uri))
+        if not os.path.exists(full):
+            return None, uri
+        return open(full, "rb").read(), uri
+    bv = doc["bufferViews"][img["bufferView"]]
+    start = bv.get("byteOffset", 0)
+    return bytes(buffers[bv["buffer"]][start:start + bv["byteLength"]]), f"bufferView {img['bufferView']}"
+
+
+def _texture_image(doc, info) -> Optional[int]:
+    """textureInfo -> index into images[] (through textures[].source)"""
+    if not info or "index" not in info:
+        return None
+    tex = doc.get("textures", [])[info["index"]]
+    return tex.get("source")
+
+
+def load(path: str, images: bool = False) -> Model:
     if not os.path.exists(path):
         raise ResourceError(f"File not found: {path}")                      # model.rs:113-115
     try:
@@ -116,9 +158,34 @@ def load(path: str) -> Model:
     for m in doc.get("materials", []):                                       # model.rs:273-309
         pbr = m.get("pbrMetallicRoughness", {})
         em = m.get("emissiveFactor", [0.0, 0.0, 0.0])
-        materials.append(Material(tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])), float(pbr.get("metallicFactor", 1.0)),
-                                  float(pbr.get("roughnessFactor", 1.0)), 1.0, (em[0], em[1], em[2], 1.0)))
-    model = Model(materials=materials, aabb_min=np.full(3, np.finfo(np.float32).max, dtype=np.float32),
+        mat = Material(tuple(pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])), float(pbr.get("metallicFactor", 1.0)),
+                       float(pbr.get("roughnessFactor", 1.0)), 1.0, (em[0], em[1], em[2], 1.0))
+        if images:
+            mat.base_color_image = _texture_image(doc, pbr.get("baseColorTexture"))
+            mat.metallic_roughness_image = _texture_image(doc, pbr.get("metallicRoughnessTexture"))
+            mat.normal_image = _texture_image(doc, m.get("normalTexture"))
+            mat.occlusion_image = _texture_image(doc, m.get("occlusionTexture"))
+            mat.emissive_image = _texture_image(doc, m.get("emissiveTexture"))
+            mat.normal_scale = float((m.get("normalTexture") or {}).get("scale", 1.0))
+            mat.occlusion_strength = float((m.get("occlusionTexture") or {}).get("strength", 1.0))
+            mat.alpha_mode = m.get("alphaMode", "OPAQUE")
+            mat.alpha_cutoff = float(m.get("alphaCutoff", 0.5))
+            mat.double_sided = bool(m.get("doubleSided", False))
+        materials.append(mat)
+    decoded, missing = [], []
+    if images:
+        from . import images as _images
+        for img in doc.get("images", []):
+            data, label = _image_bytes(doc, buffers, base, img)
+            if data is None:
+                decoded.append(None)
+                missing.append(label)
+                continue
+            try:
+                decoded.append(_images.decode_image(data))
+            except _images.ImageDecodeError as e:
+                raise ResourceError(f"Failed to decode image {label} of {path}: {e}")
+    model = Model(materials=materials, images=decoded, missing_images=missing, aabb_min=np.full(3, np.finfo(np.float32).max, dtype=np.float32),
                   aabb_max=np.full(3, np.finfo(np.float32).min, dtype=np.float32))
     for mesh in doc.get("meshes", []):
         for prim in mesh.get("primitives", []):

@@ -1,7 +1,11 @@
 // gltf.hpp -- C++ mirror of `Model::load` (crates/resources/src/model.rs:111-270): glTF 2.0 (.gltf + .bin or data: URIs)
 // -> SoA meshes with the reference's defaults, materials (model.rs:273-309), AABB.  Node transforms are NOT applied
-// (model.rs:135-144); images are not decoded (the reference discards them, model.rs:120).  Header-only, no dependency:
-// the JSON reader below covers the subset glTF uses (objects, arrays, strings, numbers, true/false/null).
+// (model.rs:135-144).  Images: the reference lets gltf::import decode them and discards the result (model.rs:120), and so
+// does load(path); load(path, ImagePolicy::Decode) keeps them -- every images[i] (file URI, data: URI, bufferView) goes
+// through image_decode.hpp to RGBA8 and each material records the image behind its five texture slots
+// (model_pbr.hlsl:62-95, t0..t4).  A file that is absent becomes an empty optional and is listed in missing_images.
+// Header-only, no dependency: the JSON reader below covers the subset glTF uses (objects, arrays, strings, numbers,
+// true/false/null).
 // the caller side of the hot path -- its output feeds Mesh::interleave() -> `Vertex` streams.
 #ifndef MIRHI_GLTF_HPP
 #define MIRHI_GLTF_HPP
@@ -18,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "image_decode.hpp"
 #include "mirhi.hpp"
 
 namespace mirhi {
@@ -105,14 +110,27 @@ private:
 
 struct LoadedMesh : Mesh { std::optional<size_t> material_index; size_t vertex_count() const { return positions.size(); } size_t triangle_count() const { return indices.size() / 3; } };
 
+enum class ImagePolicy { Discard, Decode };
+
+// what a glTF material says about textures and alpha, next to the reference's `Material` (factors only, material.rs:6-30)
+struct MaterialTextures {
+    std::optional<size_t> base_color, metallic_roughness, normal, occlusion, emissive;   // indices into Model::images
+    float normal_scale = 1.0f, occlusion_strength = 1.0f, alpha_cutoff = 0.5f;
+    std::string alpha_mode = "OPAQUE";
+    bool double_sided = false;
+};
+
 struct Model {   // model.rs:46-109
     std::vector<LoadedMesh> meshes;
     std::vector<Material> materials;
+    std::vector<MaterialTextures> material_textures;      // parallel to materials; filled by ImagePolicy::Decode
+    std::vector<std::optional<ImageData>> images;         // one per glTF image (ImagePolicy::Decode)
+    std::vector<std::string> missing_images;
     Vec3 aabb_min{FLT_MAX, FLT_MAX, FLT_MAX}, aabb_max{-FLT_MAX, -FLT_MAX, -FLT_MAX};
     size_t total_vertices() const { size_t n = 0; for (auto& m : meshes) n += m.vertex_count(); return n; }
     size_t total_triangles() const { size_t n = 0; for (auto& m : meshes) n += m.triangle_count(); return n; }
 
-    static Model load(const std::string& path) {
+    static Model load(const std::string& path, ImagePolicy policy = ImagePolicy::Discard) {
         std::ifstream f(path, std::ios::binary);
         if (!f) throw ResourceError("File not found: " + path);                         // model.rs:113-115
         std::stringstream ss; ss << f.rdbuf();
@@ -145,6 +163,47 @@ struct Model {   // model.rs:46-109
             if (m.has("emissiveFactor")) { const json::Value& e = m.at("emissiveFactor"); out.emissive = {(float)e.at(0).num, (float)e.at(1).num, (float)e.at(2).num, 1.0f}; }
             else out.emissive = {0, 0, 0, 1.0f};
             model.materials.push_back(out);
+            if (policy == ImagePolicy::Decode) {
+                MaterialTextures t;
+                auto source = [&](const json::Value& owner, const char* key) -> std::optional<size_t> {
+                    if (!owner.has(key) || !owner.at(key).has("index") || !doc.has("textures")) return std::nullopt;
+                    const json::Value& tex = doc.at("textures").at((size_t)owner.at(key).at("index").num);
+                    if (!tex.has("source")) return std::nullopt;
+                    return (size_t)tex.at("source").num;
+                };
+                if (m.has("pbrMetallicRoughness")) {
+                    t.base_color = source(m.at("pbrMetallicRoughness"), "baseColorTexture");
+                    t.metallic_roughness = source(m.at("pbrMetallicRoughness"), "metallicRoughnessTexture");
+                }
+                t.normal = source(m, "normalTexture"); t.occlusion = source(m, "occlusionTexture"); t.emissive = source(m, "emissiveTexture");
+                if (m.has("normalTexture")) t.normal_scale = (float)m.at("normalTexture").get("scale", 1.0);
+                if (m.has("occlusionTexture")) t.occlusion_strength = (float)m.at("occlusionTexture").get("strength", 1.0);
+                if (m.has("alphaMode")) t.alpha_mode = m.at("alphaMode").str;
+                t.alpha_cutoff = (float)m.get("alphaCutoff", 0.5);
+                t.double_sided = m.has("doubleSided") && m.at("doubleSided").b;
+                model.material_textures.push_back(t);
+            }
+        }
+        if (policy == ImagePolicy::Decode && doc.has("images")) for (size_t i = 0; i < doc.at("images").size(); i++) {
+            const json::Value& img = doc.at("images").at(i);
+            std::vector<uint8_t> bytes; std::string label;
+            if (img.has("uri")) {
+                const std::string uri = img.at("uri").str; label = uri;
+                if (uri.rfind("data:", 0) == 0) { bytes = base64(uri.substr(uri.find(',') + 1)); label = "data: URI"; }
+                else {
+                    std::ifstream imf(base + "/" + percent_decode(uri), std::ios::binary);
+                    if (!imf) { model.images.emplace_back(std::nullopt); model.missing_images.push_back(uri); continue; }
+                    bytes.assign((std::istreambuf_iterator<char>(imf)), std::istreambuf_iterator<char>());
+                }
+            } else if (img.has("bufferView")) {
+                const json::Value& bv = doc.at("bufferViews").at((size_t)img.at("bufferView").num);
+                const std::vector<uint8_t>& raw = buffers.at((size_t)bv.at("buffer").num);
+                const size_t start = (size_t)bv.get("byteOffset", 0), len = (size_t)bv.at("byteLength").num;
+                if (start + len > raw.size()) throw ResourceError("glTF: image bufferView exceeds its buffer");
+                bytes.assign(raw.begin() + start, raw.begin() + start + len); label = "bufferView";
+            } else throw ResourceError("glTF: image " + std::to_string(i) + " has neither uri nor bufferView");
+            try { model.images.emplace_back(decode_image(bytes.data(), bytes.size())); }
+            catch (const ImageError& e) { throw ResourceError("Failed to decode image " + label + " of " + path + ": " + e.what()); }
         }
         if (doc.has("meshes")) for (size_t mi = 0; mi < doc.at("meshes").size(); mi++) {
             const json::Value& mesh = doc.at("meshes").at(mi);
@@ -178,6 +237,15 @@ struct Model {   // model.rs:46-109
     }
 
 private:
+    static std::string percent_decode(const std::string& s) {
+        std::string out;
+        for (size_t i = 0; i < s.size(); i++) {
+            if (s[i] == '%' && i + 2 < s.size() + 0 && isxdigit((unsigned char)s[i + 1]) && isxdigit((unsigned char)s[i + 2])) {
+                out.push_back((char)std::stoi(s.substr(i + 1, 2), nullptr, 16)); i += 2;
+            } else out.push_back(s[i]);
+        }
+        return out;
+    }
     static std::vector<uint8_t> base64(const std::string& s) {
         std::vector<uint8_t> out; uint32_t acc = 0; int bits = 0;
         for (char c : s) {

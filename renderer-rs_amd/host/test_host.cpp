@@ -93,6 +93,16 @@ static void cpu_tests() {
         bool threw = false;
         try { resources::Model::load("/nonexistent/file.gltf"); } catch (const resources::ResourceError& e) { threw = std::strstr(e.what(), "File not found") != nullptr; }
         CHECK(threw);
+        // images kept (ImagePolicy::Decode): the fixture ships the normal map only; the two absent files are reported, not fatal
+        const resources::Model mt = resources::Model::load(gltf, resources::ImagePolicy::Decode);
+        CHECK(m.images.empty() && m.material_textures.empty());                    // default = the reference's behaviour
+        CHECK(mt.images.size() == 3 && !mt.images[0] && !mt.images[1] && mt.images[2].has_value() && mt.missing_images.size() == 2);
+        CHECK(mt.images[2]->width == 1024 && mt.images[2]->height == 1024 && mt.images[2]->rgba.size() == 1024u * 1024u * 4u && mt.images[2]->source_channels == 3);
+        uint64_t sum[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < mt.images[2]->rgba.size(); i++) sum[i & 3] += mt.images[2]->rgba[i];
+        CHECK(sum[3] == 255ull * 1024 * 1024 && sum[2] > sum[0] && sum[2] > sum[1]);   // opaque, and blue-dominant like any tangent-space normal map
+        CHECK(mt.material_textures.size() == 1 && *mt.material_textures[0].normal == 2 && *mt.material_textures[0].base_color == 0 &&
+              *mt.material_textures[0].metallic_roughness == 1 && !mt.material_textures[0].occlusion && mt.material_textures[0].double_sided);
     }
     // no GPU -> NoSuitableGpu, never a fallback
     int32_t n = 0; mirhi_device_count(&n);

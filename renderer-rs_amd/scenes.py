@@ -730,22 +730,55 @@ def mip_ground_case(width: int = 240, height: int = 150) -> Scene:
 
 
 def gltf_model(path: str, width: int = 1920, height: int = 1080, program: int = PROGRAM_MODEL_FULL,
-               eye=(0.0, 0.0, 3.2), yaw: float = 0.4) -> Scene:
+               eye=(0.0, 0.0, 3.2), yaw: float = 0.4, textures: bool = False) -> Scene:
     """A glTF asset through the reference's loader semantics (gltf.load) -> `Vertex` streams, lit like config 3:
-    1 point light, base colour 0.7, roughness 0.5, white 1x1 albedo / "no normal map" textures."""
+    1 point light, base colour 0.7, roughness 0.5, white 1x1 albedo / "no normal map" textures.
+
+    textures=True binds the asset's own images where its files exist (gltf.load(images=True)): base colour as
+    R8G8B8A8_SRGB, normal / metallic-roughness / occlusion as UNORM, all with a mip chain and trilinear sampling
+    (model_pbr.hlsl:62-95 slot order); the material's factors replace the config-3 constants."""
     from . import gltf
-    model = gltf.load(path)
+    model = gltf.load(path, images=textures)
     view, proj, cam = default_camera(width, height, eye=eye)
     obj = object_ubo(trs((1.0, 1.0, 1.0), quat_axis_angle((0.0, 1.0, 0.0), yaw), (0.0, 0.0, 0.0)))
+    cache = {}
+
+    def tex(index, srgb=False):
+        if not textures or index is None or index >= len(model.images) or model.images[index] is None:
+            return None
+        if (index, srgb) not in cache:
+            cache[(index, srgb)] = Texture(model.images[index].rgba, mips=True, srgb=srgb)
+        return cache[(index, srgb)]
+
     draws = []
     for mesh in model.meshes:
+        mat = model.materials[mesh.material_index] if textures and mesh.material_index is not None and mesh.material_index < len(model.materials) else None
+        maps = dict(albedo_map=WHITE_1X1, normal_map=WHITE_1X1)
+        material = (pbr_material_ubo((0.7, 0.7, 0.7, 1.0), 0.0, 0.5, 1.0) if program == PROGRAM_MODEL_PBR
+                    else material_ubo((0.7, 0.7, 0.7, 1.0), 0.0, 0.5, 1.0))
+        if program == PROGRAM_MODEL_PBR:
+            maps.update(metallic_roughness_map=WHITE_1X1, occlusion_map=WHITE_1X1, emissive_map=WHITE_1X1)
+        if mat is not None:
+            maps["albedo_map"] = tex(mat.base_color_image, srgb=True) or WHITE_1X1
+            maps["normal_map"] = tex(mat.normal_image) or WHITE_1X1
+            if program == PROGRAM_MODEL_PBR:
+                slots = {"metallic_roughness_map": tex(mat.metallic_roughness_image), "occlusion_map": tex(mat.occlusion_image),
+                         "emissive_map": tex(mat.emissive_image, srgb=True)}
+                maps.update({k: v or WHITE_1X1 for k, v in slots.items()})
+                material = pbr_material_ubo(mat.base_color, mat.metallic, mat.roughness, mat.ao, normal_scale=mat.normal_scale,
+                                            emissive=mat.emissive[:3], has_base_color=maps["albedo_map"] is not WHITE_1X1,
+                                            has_normal=maps["normal_map"] is not WHITE_1X1,
+                                            has_metallic_roughness=slots["metallic_roughness_map"] is not None,
+                                            has_occlusion=slots["occlusion_map"] is not None, has_emissive=slots["emissive_map"] is not None)
+            else:
+                material = material_ubo(mat.base_color, mat.metallic, mat.roughness, mat.ao)
         draws.append(DrawSpec(vertices=mesh.interleave(), stride=48, count=int(mesh.indices.size), indices=mesh.indices,
                               program=program, cull_mode=CULL_NONE, front_face=FRONT_CCW, camera=cam, object=obj,
                               light=light_ubo(direction=(0.0, -1.0, 0.0), intensity=0.0, num_point=1),
-                              material=material_ubo((0.7, 0.7, 0.7, 1.0), 0.0, 0.5, 1.0),
-                              point_lights=point_light((2.0, 2.0, 2.0), 10.0, (1.0, 1.0, 1.0), 5.0),
-                              albedo_map=WHITE_1X1, normal_map=WHITE_1X1))
-    return Scene(f"gltf-{os.path.basename(os.path.dirname(os.path.abspath(path)))}-{model.total_triangles}", width, height, draws,
+                              material=material,
+                              point_lights=point_light((2.0, 2.0, 2.0), 10.0, (1.0, 1.0, 1.0), 5.0), **maps))
+    tag = "-textured" if textures else ""
+    return Scene(f"gltf-{os.path.basename(os.path.dirname(os.path.abspath(path)))}-{model.total_triangles}{tag}", width, height, draws,
                  clear_color=(0.1, 0.1, 0.15, 1.0))
 
 

@@ -61,3 +61,70 @@ def test_dancer_scene_renders_with_oracle(oracle, scenes):
     r = oracle.render(s, want_bgra8=False)
     cov = r["prim"] != 0xFFFFFFFF
     assert 0.03 < cov.mean() < 0.6 and not np.isnan(r["rgba"]).any()
+
+
+def test_dancer_images_are_decoded_on_request(mirhi):
+    """images=True keeps what the reference discards (model.rs:120): the fixture ships the (reduced) normal map only,
+    the two files the reference's own asset directory lacks are reported and not fatal."""
+    from renderer_rs_amd import gltf
+    assert gltf.load(DANCER).images == []                              # default = the reference's behaviour
+    m = gltf.load(DANCER, images=True)
+    assert m.missing_images == ["textures/Material.001_baseColor.png", "textures/Material.001_metallicRoughness.png"]
+    assert m.images[0] is None and m.images[1] is None
+    nm = m.images[2]
+    assert nm.rgba.shape == (1024, 1024, 4) and nm.source_channels == 3 and (nm.rgba[..., 3] == 255).all()
+    from PIL import Image
+    ref = np.asarray(Image.open(os.path.join(os.path.dirname(DANCER), "textures", "Material.001_normal.png")).convert("RGBA"))
+    assert np.array_equal(nm.rgba, ref)
+    n = nm.rgba[..., :3].astype(np.float64) / 255.0 * 2.0 - 1.0         # tangent-space normals: unit length, +z
+    assert abs(np.linalg.norm(n, axis=-1).mean() - 1.0) < 0.02 and n[..., 2].mean() > 0.8
+    mat = m.materials[0]
+    assert (mat.base_color_image, mat.metallic_roughness_image, mat.normal_image, mat.occlusion_image) == (0, 1, 2, None)
+    assert mat.double_sided and mat.alpha_mode == "OPAQUE" and mat.normal_scale == 1.0
+
+
+def test_embedded_and_buffer_view_images(mirhi, tmp_path):
+    """data: URIs and bufferView-backed images (GLB-style) decode like files; a corrupt image is a ResourceError."""
+    import base64
+    import io
+    from PIL import Image
+    from renderer_rs_amd import gltf
+    rng = np.random.default_rng(1)
+    px = rng.integers(0, 256, size=(6, 5, 4), dtype=np.uint8)
+    buf = io.BytesIO(); Image.fromarray(px, "RGBA").save(buf, "PNG"); png = buf.getvalue()
+    jp = np.full((8, 8, 3), 200, dtype=np.uint8)
+    buf = io.BytesIO(); Image.fromarray(jp, "RGB").save(buf, "JPEG", quality=95); jpg = buf.getvalue()
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32).tobytes()
+    blob = pos + jpg
+    doc = {"asset": {"version": "2.0"},
+           "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+           "bufferViews": [{"buffer": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": len(jpg)}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+           "images": [{"uri": "data:image/png;base64," + base64.b64encode(png).decode()}, {"bufferView": 1, "mimeType": "image/jpeg"}],
+           "textures": [{"source": 1}, {"source": 0}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 1}}, "emissiveTexture": {"index": 0},
+                          "alphaMode": "MASK", "alphaCutoff": 0.25}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "material": 0}]}]}
+    p = tmp_path / "m.gltf"
+    p.write_text(json.dumps(doc))
+    m = gltf.load(str(p), images=True)
+    assert np.array_equal(m.images[0].rgba, px) and m.images[0].source_channels == 4
+    assert m.images[1].rgba.shape == (8, 8, 4) and abs(int(m.images[1].rgba[0, 0, 0]) - 200) <= 1
+    assert m.materials[0].base_color_image == 0 and m.materials[0].emissive_image == 1       # through textures[].source
+    assert m.materials[0].alpha_mode == "MASK" and m.materials[0].alpha_cutoff == 0.25
+    doc["images"][0]["uri"] = "data:image/png;base64," + base64.b64encode(png[:40]).decode()
+    p.write_text(json.dumps(doc))
+    with pytest.raises(gltf.ResourceError, match="decode"):
+        gltf.load(str(p), images=True)
+
+
+def test_textured_dancer_renders_with_oracle(oracle, scenes):
+    plain = oracle.render(scenes.gltf_model(DANCER, 320, 180), want_bgra8=False)
+    for program in (scenes.PROGRAM_MODEL_FULL, scenes.PROGRAM_MODEL_PBR):
+        s = scenes.gltf_model(DANCER, 320, 180, program=program, textures=True)
+        d = s.draws[0]
+        assert d.normal_map.rgba8.shape == (1024, 1024, 4) and d.normal_map.mips and d.albedo_map.rgba8.shape == (1, 1, 4)
+        r = oracle.render(s, want_bgra8=False)
+        assert np.array_equal(r["prim"], plain["prim"]) and not np.isnan(r["rgba"]).any()
+        cov = r["prim"] != 0xFFFFFFFF
+        assert np.abs(r["rgba"][cov] - plain["rgba"][cov]).max() > 0.01          # the normal map changes the lighting

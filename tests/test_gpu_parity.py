@@ -130,6 +130,19 @@ def test_gltf_dancer_1080p(mirhi, oracle, device, scenes):
     _check(out, ref, scene.name, depth=True)
 
 
+@pytest.mark.parametrize("program", ["full", "pbr"])
+def test_gltf_dancer_with_its_normal_map(mirhi, oracle, device, scenes, program):
+    """SURVEY 8f rank 1, texture half: the asset's own normal map (PNG -> RGBA8 by host/image_decode.hpp, mip chain on the
+    device, trilinear) drives model_full / model_pbr shading of the real mesh."""
+    import os
+    prog = scenes.PROGRAM_MODEL_FULL if program == "full" else scenes.PROGRAM_MODEL_PBR
+    scene = scenes.gltf_model(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dancer", "scene.gltf"),
+                              program=prog, textures=True)
+    assert scene.draws[0].normal_map.rgba8.shape == (1024, 1024, 4)
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=True)
+    _check(out, ref, scene.name, depth=True)
+
+
 def test_submission_order_does_not_change_depth(mirhi, device, scenes):
     """Size-independent property at BASELINE configs[1] size: with LESS and distinct depths the stored depth image is a
     function of the triangle SET; reversing the submission order must leave it bit-identical (and permute prim ids)."""
