@@ -253,7 +253,7 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 
 // Stages up to RASTER_THREADS triangle records of `list` (bin or big list) into LDS as tile records
 // (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
-template <int KEYED, int TP>
+template <int KEYED, int TP, int CHUNK>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
@@ -263,7 +263,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
     // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
     const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
-    for (uint32_t base = 0; base < n_total; base += RASTER_CHUNK) {
+    for (uint32_t base = 0; base < n_total; base += (uint32_t)CHUNK) {
         if (tid == 0) *lds_count = 0;
         __syncthreads();
         // opaque copies: what make_tile_rec derives from the tile coordinates is rebuilt per chunk (a few instructions)
@@ -273,7 +273,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         const uint32_t i = base + ftid;
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
-        if (ftid < RASTER_CHUNK && i < n_total) {
+        if (ftid < (uint32_t)CHUNK && i < n_total) {
             // all three words are requested together: one memory round trip, not two (a bin holds only records whose
             // box overlaps the tile, so the box test below almost never saves the first two loads)
             const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
@@ -323,7 +323,11 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 template <int PROGS, int KEYED, int TP>
 __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
-    __shared__ uint4 lds_rec[RASTER_CHUNK * 4];
+    // mesh variants stage with all four waves: their small records are resolved while staging (triangle-parallel), so a
+    // hot tile's serial chain is one pass per CHUNK records; the sparse variants keep 192 (LDS per workgroup bounds
+    // their 7-8 workgroups per CU)
+    constexpr int CHUNK = (TP && PROGS >= 2) ? RASTER_THREADS : RASTER_CHUNK;
+    __shared__ uint4 lds_rec[CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
     __shared__ uint32_t lds_count;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     uint32_t n_list = count;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP>(list, n_list, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+        if (n_list) raster_list<KEYED, TP, CHUNK>(list, n_list, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
