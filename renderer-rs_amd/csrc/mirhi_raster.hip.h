@@ -255,7 +255,7 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
 template <int KEYED, int TP, int CHUNK>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
-                                            uint32_t* lds_count, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
+                                            uint32_t* lds_count, uint32_t& flip, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
                                             uint32_t lane) {
@@ -264,8 +264,13 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
     const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
     for (uint32_t base = 0; base < n_total; base += (uint32_t)CHUNK) {
-        if (tid == 0) *lds_count = 0;
+        // Two staging counters used alternately: the one of this pass was zeroed during the previous pass (or at kernel
+        // entry), the other one is re-armed here, behind the barrier that every wave reaches only after it has read that
+        // counter as the previous pass's record count.  (A single counter zeroed in front of the barrier could be cleared
+        // under a wave that an instruction-cache miss held up between the previous barrier and that read.)
         __syncthreads();
+        uint32_t* const cnt = lds_count + flip;
+        if (tid == 0) lds_count[flip ^ 1u] = 0;
         // opaque copies: what make_tile_rec derives from the tile coordinates is rebuilt per chunk (a few instructions)
         // instead of being hoisted out of the loops into VGPRs that then spill
         uint32_t txl = tx, tyl = ty;
@@ -300,7 +305,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         }
         const uint64_t ball = __ballot(hit);
         uint32_t wbase = 0;
-        if (lane == 0 && ball) wbase = atomicAdd(lds_count, (uint32_t)__popcll(ball));
+        if (lane == 0 && ball) wbase = atomicAdd(cnt, (uint32_t)__popcll(ball));
         wbase = __builtin_amdgcn_readfirstlane(wbase);
         if (hit) {
             const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
@@ -309,7 +314,8 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             if (!TP) lds_box[slot] = box;
         }
         __syncthreads();
-        const uint32_t n = *lds_count;
+        const uint32_t n = *cnt;
+        flip ^= 1u;
         if (base == 0) { STAMP(5); STAGE_END(2u); }
         if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
     }
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     __shared__ uint4 lds_rec[CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
-    __shared__ uint32_t lds_count;
+    __shared__ uint32_t lds_count[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
     // (one contiguous band of tiles per XCD measured 20-30 % slower on unevenly covered frames: runs stay interleaved)
@@ -370,6 +376,8 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
         P.status[1] = nbig_raw;
     }
 
+    if (tid == 0) { lds_count[0] = 0; lds_count[1] = 0; }      // staging counters of raster_list (ordered by its first barrier)
+    uint32_t flip = 0;
     if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
     PixelState st;
 #pragma unroll
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     uint32_t n_list = count;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP, CHUNK>(list, n_list, lds_rec, lds_box, &lds_count, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+        if (n_list) raster_list<KEYED, TP, CHUNK>(list, n_list, lds_rec, lds_box, lds_count, flip, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
