@@ -3,7 +3,7 @@
 // The reference pulls `image 0.25.9` (+ png 0.18, zune-jpeg 0.5.8) through `gltf::import` and then DISCARDS the decoded
 // images (crates/resources/src/model.rs:120); its own texture types are stubs (crates/rhi/src/{image,sampler,texture}.rs
 // :1-5) while every model shader samples `Texture2D` slots (shaders/hlsl/pixel/model_full.hlsl:44-46, model_pbr.hlsl).
-// This header is what stands between `assets/textures/*.{png,jpg}` / a glTF's `images[]` and mirhi_image_write:
+// This header is what stands between `assets/textures/*.{png,jpg}` / a glTF's `images[]` and mirhi_image_upload:
 //
 //   decode_png   all colour types (0,2,3,4,6), bit depths 1..16, tRNS, Adam7; chunk CRCs and the zlib Adler-32 are checked.
 //                16-bit samples narrow with the `image` crate's rule (c + 128) / 257.  Bit-exact by construction.
