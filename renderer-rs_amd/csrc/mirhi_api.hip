@@ -1141,6 +1141,12 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             const bool dense = tiles && (pass.total_tris - pass.first_tri) / tiles >= density;
             P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 64u : 0u);
             if (P.pred) P.tp_max_area = 0;    // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
+            // Two teams per tile when a mesh scope is dense enough for the triangle-parallel variant yet averages under 16
+            // triangles per tile: then its triangles sit in a small part of the frame (the dancer asset: 8 on average, 124
+            // per tile it touches, 919 in the fullest), the chip is far from full and the kernel's duration is the fullest
+            // tile's serial chain -- which two teams cut (dancer raster 62.6 -> 44.0 us; four teams: 47.4).  MIRHI_RASTER_TEAMS (1 / 2) overrides.
+            const size_t avg = tiles ? (pass.total_tris - pass.first_tri) / tiles : 0;
+            P.raster_teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : ((P.tp_max_area && !tri_prog && avg < 16) ? 2u : 1u);
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();

@@ -122,6 +122,7 @@ struct PassParams {
     uint32_t tp_max_area;             // records whose pixel box inside the tile has at most this many pixels are resolved
                                       // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
+    uint32_t raster_teams;            // 2: the mesh variant with two teams of four waves per tile (host-side choice, see raster_kernel)
     // ordered segments (blending; any depth state whose result depends on the order of all fragments): the geometry kernel
     // writes triangle t of the segment to ordered_recs[t] instead of binning it, the ordered kernel walks that array
     TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;

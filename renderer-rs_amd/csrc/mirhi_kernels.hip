@@ -53,9 +53,14 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
     return hipGetLastError();
 }
 
-template <int KEYED, int TP>
+template <int KEYED, int TP, int TEAMS = 1>
 static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream) {
-    const dim3 block(RASTER_THREADS);
+    const dim3 block(RASTER_THREADS * TEAMS);
+    if (TEAMS > 1) {            // only the pure mesh variants exist with two teams (launch_raster checks)
+        if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP, TEAMS>), grid, block, 0, stream, P, H);
+        else hipLaunchKernelGGL((raster_kernel<4, KEYED, TP, TEAMS>), grid, block, 0, stream, P, H);
+        return;
+    }
     if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P, H);
     else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P, H);
     else if (programs >= 4) hipLaunchKernelGGL((raster_kernel<4, KEYED, TP>), grid, block, 0, stream, P, H);
@@ -79,6 +84,9 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     const RasterHead H = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap};
     if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream);          // (the host keeps tp_max_area = 0 for predicate scopes)
+    else if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) {
+        if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream);
+    }
     else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream); }
     else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream); }
     return hipGetLastError();

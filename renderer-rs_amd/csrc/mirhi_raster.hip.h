@@ -253,9 +253,12 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 
 // Stages up to RASTER_THREADS triangle records of `list` (bin or big list) into LDS as tile records
 // (one record per lane, wave ballot + prefix popcount compaction), then resolves them.
-template <int KEYED, int TP, int CHUNK>
+// TEAMS > 1 (mesh variants): the workgroup is TEAMS sets of four waves; team t stages and rasters chunks t, t + TEAMS, ...
+// of the list into its own staging area and its own register keys (tid = lane index within the team).  Every team runs
+// the same number of passes -- the barriers are workgroup-wide -- a team whose chunk lies beyond the list stages nothing.
+template <int KEYED, int TP, int CHUNK, int TEAMS>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
-                                            uint32_t* lds_count, uint32_t& flip, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
+                                            uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
                                             uint32_t lane) {
@@ -263,7 +266,8 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
     // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
     const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
-    for (uint32_t base = 0; base < n_total; base += (uint32_t)CHUNK) {
+    for (uint32_t base0 = 0; base0 < n_total; base0 += (uint32_t)CHUNK * (TEAMS > 1 ? nteams : 1u)) {
+        const uint32_t base = base0 + team * (uint32_t)CHUNK;
         // Two staging counters used alternately: the one of this pass was zeroed during the previous pass (or at kernel
         // entry), the other one is re-armed here, behind the barrier that every wave reaches only after it has read that
         // counter as the previous pass's record count.  (A single counter zeroed in front of the barrier could be cleared
@@ -316,7 +320,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         __syncthreads();
         const uint32_t n = *cnt;
         flip ^= 1u;
-        if (base == 0) { STAMP(5); STAGE_END(2u); }
+        if (base0 == 0) { STAMP(5); STAGE_END(2u); }
         if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
     }
 }
@@ -326,19 +330,26 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // other variants no registers)
 // TP: 1 = the triangle-parallel path (LDS key array) is compiled in; the host enables it for scopes with many
 //     triangles per tile, sparse scopes use the leaner pixel-parallel-only variant
-template <int PROGS, int KEYED, int TP>
-__global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+// TEAMS = 2 (mesh variants of scopes whose triangles sit in a small part of the frame, PassParams::raster_teams): two sets
+// of four waves per tile.  A real mesh is bound by its fullest tiles -- one workgroup per tile is one serial chain of
+// staging passes while most of the chip idles -- and the teams split that chain: alternate chunks of the bin, keys merged
+// through LDS at the end, then each team shades half of the tile's pixels.  No traffic through memory and no extra
+// workgroups, unlike sharing a tile between workgroups ("measured and not adopted").  On frames that already
+// fill the chip the wider workgroups only cost occupancy (C4 raster 109 -> 156 us, C5 202 -> 272 us), hence the host's choice.
+template <int PROGS, int KEYED, int TP, int TEAMS = 1>
+__global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     // mesh variants stage with all four waves: their small records are resolved while staging (triangle-parallel), so a
     // hot tile's serial chain is one pass per CHUNK records; the sparse variants keep 192 (LDS per workgroup bounds
     // their 7-8 workgroups per CU)
     constexpr int CHUNK = (TP && PROGS >= 2) ? RASTER_THREADS : RASTER_CHUNK;
-    __shared__ uint4 lds_rec[CHUNK * 4];
+    __shared__ uint4 lds_rec[TEAMS][CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
-    __shared__ uint32_t lds_count[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keep it in SGPRs
+    __shared__ uint32_t lds_count[TEAMS * 2];
+    const uint32_t tid = threadIdx.x & (RASTER_THREADS - 1u), lane = tid & 63u;       // tid: index within the team
+    const uint32_t team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index within the team: uniform, keep it in SGPRs
     // (one contiguous band of tiles per XCD measured 20-30 % slower on unevenly covered frames: runs stay interleaved)
     // Plain order: a 2-D grid, (blockIdx.x, blockIdx.y) = (tile column, tile row of the band): no division.
     // P.xcd_swizzle > 1 (1-D grid): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD, each XCD
@@ -367,22 +378,26 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     const uint32_t nbig_raw = *H.big_count;
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
+    // (Letting the second team leave tiles whose lists fit one staging pass was measured: the scopes that get this variant
+    // leave most of the chip idle anyway, and those tiles then lose the split resolve: dancer 43 -> 46 us, 49 -> 57 us textured.)
+    constexpr bool solo = TEAMS == 1;
+    constexpr uint32_t nteams = (uint32_t)TEAMS;
     // The big-list counters are re-armed right away (no workgroup reads the other parity's counter, and the next scope
     // that uses this workspace is ordered behind this kernel), so nbig_raw need not stay live across the raster loops.
     // The tile's own bin counter is re-armed after the bin pass: every wave of this workgroup reads it above, and the
     // barriers of that pass order those reads before the store.
-    if (tid == 0 && tile == 0) {
+    if (tid == 0 && team == 0 && tile == 0) {
         *P.big_count_next = 0;                              // the next scope on this workspace appends to the other counter
         P.status[1] = nbig_raw;
     }
 
-    if (tid == 0) { lds_count[0] = 0; lds_count[1] = 0; }      // staging counters of raster_list (ordered by its first barrier)
+    if (tid == 0) { lds_count[2u * team] = 0; lds_count[2u * team + 1u] = 0; }      // this team's staging counters (ordered by raster_list's first barrier)
     uint32_t flip = 0;
-    if (TP) for (uint32_t e = tid; e < TILE * TILE; e += RASTER_THREADS) lds_key[e] = ~0ull;
+    if (TP) for (uint32_t e = tid + team * RASTER_THREADS; e < TILE * TILE; e += RASTER_THREADS * nteams) lds_key[e] = ~0ull;
     PixelState st;
 #pragma unroll
     for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
-    if (P.depth_load && P.depth) {              // second scope on a kept depth buffer: keys start from the stored depth
+    if (P.depth_load && P.depth && team == 0) { // second scope on a kept depth buffer: keys start from the stored depth (one team's keys)
         const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -399,11 +414,11 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     uint32_t n_list = count;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP, CHUNK>(list, n_list, lds_rec, lds_box, lds_count, flip, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
-            if (count && tid == 0) H.bin_count[tile] = 0;   // ready for the next scope that uses this workspace
+            if (count && tid == 0 && team == 0) H.bin_count[tile] = 0;   // ready for the next scope that uses this workspace
             if (!nbig) break;
             // parameters of this phase are (re)read here, see launder_params
             list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
 
     STAMP(3);
     STAGE_END(3u);
-    if (TP) __syncthreads();     // every triangle-parallel ds_min of this tile has landed
+    if (TP || TEAMS > 1) __syncthreads();     // every triangle-parallel ds_min of this tile has landed; staging areas are free
     // ---- resolve: shade the winning primitive of each pixel, store once ---------------------------
     // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
     if (TP) {
@@ -423,6 +438,37 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
             const unsigned long long klds = lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK];
             const unsigned long long kmin = klds < kreg ? klds : kreg;
             st.zk[b] = (uint32_t)(kmin >> 32); st.idk[b] = (uint32_t)kmin;
+        }
+    }
+    if (TEAMS > 1 && !solo) {
+        // merge the teams' keys through their (now idle) staging areas: teams > 0 publish, team 0 takes the minimum and
+        // publishes the result, everyone reads it back; then team t shades blocks [4t/TEAMS, 4(t+1)/TEAMS) of each lane
+        unsigned long long* const mine = reinterpret_cast<unsigned long long*>(&lds_rec[team][0]);
+        if (team != 0u) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) mine[b * RASTER_THREADS + tid] = ((unsigned long long)st.zk[b] << 32) | st.idk[b];
+        }
+        __syncthreads();
+        if (team == 0u) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                unsigned long long k = ((unsigned long long)st.zk[b] << 32) | st.idk[b];
+#pragma unroll
+                for (int t = 1; t < TEAMS; t++) {
+                    const unsigned long long o = reinterpret_cast<const unsigned long long*>(&lds_rec[t][0])[b * RASTER_THREADS + tid];
+                    k = o < k ? o : k;
+                }
+                mine[b * RASTER_THREADS + tid] = k;
+                st.zk[b] = (uint32_t)(k >> 32); st.idk[b] = (uint32_t)k;
+            }
+        }
+        __syncthreads();
+        if (team != 0u) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned long long k = reinterpret_cast<const unsigned long long*>(&lds_rec[0][0])[b * RASTER_THREADS + tid];
+                st.zk[b] = (uint32_t)(k >> 32); st.idk[b] = (uint32_t)k;
+            }
         }
     }
     // The resolve reads its parameters through a laundered kernarg pointer: the scalar loads are issued here, not at
@@ -480,6 +526,7 @@ __global__ __launch_bounds__(RASTER_THREADS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS
     }
 #pragma unroll 1
     for (int b = 0; b < 4; b++) {
+        if (TEAMS > 1 && !solo && (uint32_t)(b * TEAMS) / 4u != team) continue;      // another team shades this block
         const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
         const bool inb = px < P.width && py < P.height;
         uint32_t izk, iidk, zorig;

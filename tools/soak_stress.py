@@ -40,8 +40,10 @@ for i in range(n):
     t0 = time.time()
     try:
         res = m.SceneResources(dev, scene, fmt, want_prim=True, want_depth=True)
-        res.render(); res.render(); out = res.read()
+        fence = m.Fence(dev)
+        res.render(); res.render(fence); fence.wait(); out = res.read()      # (the stats are taken when a fence completes)
         big = dev.stats().last_big_list
+        fence.destroy()
         res.destroy()
         ref = ob.render(scene, nthreads=16, want_bgra8=(i % 2 == 1))
         ok = np.array_equal(out["prim"], ref["prim"])
