@@ -397,6 +397,14 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     PixelState st;
 #pragma unroll
     for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
+    if (TEAMS > 1 && team != 0u) {
+        // The other teams start from the WORST key, one that loses every merge: team 0 alone carries the pixel's real
+        // starting state, and with a loaded depth that state may be worse than init_zk (a GREATER segment behind a LESS
+        // one: the "cleared" key would beat every loaded key and resolve to a primitive that does not exist).  Plain keys
+        // keep the top bit clear for the miss-in-the-key trick of raster_record.
+#pragma unroll
+        for (int b = 0; b < 4; b++) { st.zk[b] = KEYED == 0 ? 0x7FFFFFFFu : 0xFFFFFFFFu; st.idk[b] = 0xFFFFFFFFu; }
+    }
     if (P.depth_load && P.depth && team == 0) { // second scope on a kept depth buffer: keys start from the stored depth (one team's keys)
         const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
 #pragma unroll

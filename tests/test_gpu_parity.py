@@ -143,6 +143,32 @@ def test_gltf_dancer_with_its_normal_map(mirhi, oracle, device, scenes, program)
     _check(out, ref, scene.name, depth=True)
 
 
+@pytest.mark.parametrize("variant", ["greater", "two_states", "less_then_greater", "teams_off"])
+def test_gltf_dancer_two_team_variant_states(mirhi, oracle, device, scenes, variant, monkeypatch):
+    """The mesh raster variant with two teams of waves per tile (chosen for mesh scopes that cover a small part of the frame,
+    like this asset) under the generic depth key (GREATER against a 0.0 clear), across two segments of one scope (the
+    second one loads the depth the first one carried over, into one team's keys), and switched off for comparison."""
+    import copy
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dancer", "scene.gltf")
+    scene = scenes.gltf_model(path, 1280, 720)
+    if variant == "greater":
+        for d in scene.draws:
+            d.depth_compare = scenes.CMP_GREATER
+        scene.clear_depth = 0.0
+    elif variant in ("two_states", "less_then_greater"):
+        second = copy.copy(scene.draws[0])
+        second.object = scenes.object_ubo(scenes.trs((0.8, 0.8, 0.8), scenes.quat_axis_angle((0.0, 1.0, 0.0), 2.0), (0.3, 0.1, 0.2)))
+        # a different depth state: the scope is cut into two segments.  GREATER behind LESS is the case where the loaded
+        # depth (<= the 1.0 clear) is WORSE than the cleared key of the second segment: only one team may start from it
+        second.depth_compare = scenes.CMP_LESS_OR_EQUAL if variant == "two_states" else scenes.CMP_GREATER
+        scene.draws.append(second)
+    else:
+        monkeypatch.setenv("MIRHI_RASTER_TEAMS", "1")
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=True)
+    _check(out, ref, f"{scene.name}-{variant}", depth=True)
+
+
 def test_submission_order_does_not_change_depth(mirhi, device, scenes):
     """Size-independent property at BASELINE configs[1] size: with LESS and distinct depths the stored depth image is a
     function of the triangle SET; reversing the submission order must leave it bit-identical (and permute prim ids)."""
