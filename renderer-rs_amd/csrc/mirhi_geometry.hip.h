@@ -275,6 +275,7 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
     if (gsize) raw = atomicAdd(&P.bin_count[tile], gsize);
     return raw;
 }
+template <uint32_t BATCH>
 __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
                                                    uint32_t* lds_meta, uint16_t* lds_owner) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -325,37 +326,41 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         }
     }
     __syncthreads();            // one wave per workgroup: orders the LDS writes above before the reads below
-    // All returning atomics of the wave (one instruction per 64 pairs, reserve_bin_slots) are issued before the first
-    // result is consumed.
-    constexpr uint32_t ROUNDS = PAIR_MAX / GEOM_THREADS;
-    uint32_t raw[ROUNDS];      // atomic result (held by the reserving lane)
-    uint32_t who[ROUNDS];      // reserving lane | rank within its group << 8
+    // The returning atomics of up to BATCH rounds (one instruction per 64 pairs, reserve_bin_slots) are issued before the
+    // first result is consumed; a wave with more pairs takes another batch.  BATCH = 8 for the small-scope variant of the kernel: with four, C2 (about
+    // 320 pairs a wave) paid a second serial round trip, 7.4 -> 8.2 us; 4 for the occupancy-oriented one (8 spills at 72 VGPRs).
+    // (All sixteen possible rounds in one batch held 32 result registers live and kept the kernel at 86 VGPRs.)
+#pragma unroll 1
+    for (uint32_t it0 = 0; it0 * GEOM_THREADS < total; it0 += BATCH) {
+        uint32_t raw[BATCH];       // atomic result (held by the reserving lane)
+        uint32_t who[BATCH];       // reserving lane | rank within its group << 8
 #pragma unroll
-    for (uint32_t it = 0; it < ROUNDS; it++) {
-        raw[it] = 0; who[it] = lane;
-        if (it * GEOM_THREADS >= total) break;
-        const uint32_t p = it * GEOM_THREADS + lane;
-        const bool act = p < total;
-        uint32_t tile = 0;
-        if (act) {
-            const uint32_t o = lds_owner[p], kk = o >> 8;
-            tile = lds_meta[o & 0xFFu] + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);   // (flag bit not set yet)
+        for (uint32_t k = 0; k < BATCH; k++) {
+            raw[k] = 0; who[k] = lane;
+            const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
+            if ((it0 + k) * GEOM_THREADS >= total) continue;
+            const bool act = p < total;
+            uint32_t tile = 0;
+            if (act) {
+                const uint32_t o = lds_owner[p], kk = o >> 8;
+                tile = (lds_meta[o & 0xFFu] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
+            }
+            raw[k] = reserve_bin_slots(P, act, tile, lane, lt, who[k]);
         }
-        raw[it] = reserve_bin_slots(P, act, tile, lane, lt, who[it]);
-    }
 #pragma unroll
-    for (uint32_t it = 0; it < ROUNDS; it++) {
-        if (it * GEOM_THREADS >= total) break;
-        const uint32_t p = it * GEOM_THREADS + lane;
-        const uint32_t slot = (uint32_t)__shfl((int)raw[it], (int)(who[it] & 0xFFu)) + (who[it] >> 8);
-        if (p < total) {
-            const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
-            const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
-            if (slot < P.bin_cap) {
-                uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u;
-                dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
-            } else {
-                atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once
+        for (uint32_t k = 0; k < BATCH; k++) {
+            if ((it0 + k) * GEOM_THREADS >= total) continue;
+            const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
+            const uint32_t slot = (uint32_t)__shfl((int)raw[k], (int)(who[k] & 0xFFu)) + (who[k] >> 8);
+            if (p < total) {
+                const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
+                const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
+                if (slot < P.bin_cap) {
+                    uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u;
+                    dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
+                } else {
+                    atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once
+                }
             }
         }
     }
@@ -367,10 +372,18 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
 // One wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer
 // and pipeline-state word) is wave-uniform and lives in SGPRs.  One lane per triangle up to the screen-space setup,
 // then bin_triangle_pairs.
-__global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
+// WAVES: resident waves per SIMD the register allocation aims at.  7 (72 VGPRs) for scopes with enough triangles to fill the
+// chip several times over (C4 geometry 61.4 -> 57.4 us); 5 (up to 102) for small scopes, where a wave is alone on its SIMD
+// and only the length of its dependent instruction stream counts (C2: 7.4 us against 8.2 with the tighter allocation).
+template <int WAVES>
+__global__ __launch_bounds__(GEOM_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
-    __shared__ f4 poly[CLIP_BATCH][2][CLIP_MAX_VERTS];   // 2.5 KB: clipping lanes take turns, 8 at a time
+    // 5.4 KB of LDS per one-wave workgroup: 30 fit a CU, which is what lets 7 waves per SIMD be resident (at 7.9 KB the LDS
+    // capped the kernel at 5).  The clipper's polygon slots (2.5 KB: clipping lanes take turns, 8 at a time) reuse the
+    // triangle staging area of the binning step, which is over by then (one wave: LDS accesses stay in program order).
     __shared__ uint4 lds_tri[GEOM_THREADS][3];
+    static_assert(sizeof(f4) * CLIP_BATCH * 2 * CLIP_MAX_VERTS <= sizeof(uint4) * GEOM_THREADS * 3, "polygon slots must fit the staging area");
+    f4 (*poly)[2][CLIP_MAX_VERTS] = reinterpret_cast<f4 (*)[2][CLIP_MAX_VERTS]>(&lds_tri[0][0]);
     __shared__ uint32_t lds_meta[GEOM_THREADS];
     __shared__ uint16_t lds_owner[PAIR_MAX];
     GSTAMP(0);
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(GEOM_THREADS) void geometry_kernel(const PassParams
             slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u);
         }
     } else
-    bin_triangle_pairs(P, valid, t, lds_tri, lds_meta, lds_owner);
+    bin_triangle_pairs<(WAVES >= 7 ? 4u : 8u)>(P, valid, t, lds_tri, lds_meta, lds_owner);
     GSTAMP(2);
     uint64_t todo = __ballot(any != 0);
     while (todo) {                                   // rare: triangles crossing the near / far / guard planes

@@ -49,7 +49,9 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t blocks = P.total_slots / GEOM_THREADS;
     const GeometryHead H = {P.draws, P.num_draws};
-    hipLaunchKernelGGL(geometry_kernel, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
+    // (more waves than the chip holds at five per SIMD: the occupancy-oriented variant)
+    if (blocks > 5u * 1024u) hipLaunchKernelGGL(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
+    else hipLaunchKernelGGL(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
     return hipGetLastError();
 }
 
