@@ -1,6 +1,6 @@
 /* miresources.h -- C ABI of the asset-decode helpers on the CALLER side of the hot path.
  *
- * Host-only (no GPU, no HIP): bytes of a PNG / baseline JPEG file -> RGBA8 rows ready for mirhi_image_upload
+ * Host-only (no GPU, no HIP): bytes of a PNG / JPEG (sequential or progressive) file -> RGBA8 rows ready for mirhi_image_upload
  * (include/mirhi.h).  Replaces what the reference obtains from its `image` / `gltf` dependencies:
  *   - `gltf::import(path)` returns `Vec<gltf::image::Data>` (pixels, format, width, height), which
  *     crates/resources/src/model.rs:120 binds to `_images` and drops;

@@ -6,7 +6,7 @@
 * materials: base colour factor, metallic, roughness, emissive; AO 1.0 (model.rs:273-309, material.rs:6-30)
 * images: the reference lets `gltf::import` decode them and discards the result (model.rs:120); `load(path)` does
   the same by default.  `load(path, images=True)` keeps them: every `images[i]` (file URI, data: URI or bufferView) is
-  decoded to RGBA8 by images.decode_image (PNG / baseline JPEG, host/image_decode.hpp), and each material carries the
+  decoded to RGBA8 by images.decode_image (PNG / JPEG, host/image_decode.hpp), and each material carries the
   image index behind its baseColor / metallicRoughness / normal / occlusion / emissive texture plus alphaMode / cutoff /
   doubleSided -- what model_full.hlsl / model_pbr.hlsl bind at t0..t4.  An image whose file is absent (the dancer asset
   names three and ships one) becomes None and is listed in `Model.missing_images`.

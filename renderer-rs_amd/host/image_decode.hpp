@@ -1,4 +1,4 @@
-// image_decode.hpp -- PNG and baseline JPEG -> RGBA8, the texture-decode half of SURVEY.md section 8f rank 1.
+// image_decode.hpp -- PNG and JPEG (sequential and progressive Huffman) -> RGBA8, the texture-decode half of SURVEY.md section 8f rank 1.
 //
 // The reference pulls `image 0.25.9` (+ png 0.18, zune-jpeg 0.5.8) through `gltf::import` and then DISCARDS the decoded
 // images (crates/resources/src/model.rs:120); its own texture types are stubs (crates/rhi/src/{image,sampler,texture}.rs
@@ -7,12 +7,14 @@
 //
 //   decode_png   all colour types (0,2,3,4,6), bit depths 1..16, tRNS, Adam7; chunk CRCs and the zlib Adler-32 are checked.
 //                16-bit samples narrow with the `image` crate's rule (c + 128) / 257.  Bit-exact by construction.
-//   decode_jpeg  baseline / extended-sequential Huffman (SOF0, SOF1), 8-bit, 1 or 3 components, any sampling factors,
-//                restart intervals.  The inverse DCT is the 13-bit fixed-point Loeffler-Ligtenberg-Moschytz scheme and
-//                the YCbCr->RGB step the 16-bit fixed-point one of the IJG decoder family, chroma upsampling the
-//                triangle ("fancy") filter for 2x1 and 2x2 -- so 4:4:4, grey and 4:2:x files decode to the same bytes
-//                as libjpeg-turbo (checked against Pillow in tests/test_image_decode_cpu.py).  Progressive (SOF2),
-//                arithmetic coding, 12-bit and CMYK files are refused with a message, never decoded approximately.
+//   decode_jpeg  sequential (SOF0, SOF1; one interleaved scan or several) and progressive (SOF2: spectral selection and
+//                successive approximation, end-of-band runs, refinement scans) Huffman files, 8-bit, 1 or 3 components,
+//                any sampling factors, restart intervals.  Coefficients are accumulated over the scans, then every block
+//                goes through the 13-bit fixed-point Loeffler-Ligtenberg-Moschytz inverse DCT, the 16-bit fixed-point
+//                YCbCr->RGB step of the IJG decoder family and the triangle ("fancy") chroma upsampling for 2x1 and
+//                2x2 -- so 4:4:4, grey and 4:2:x files decode to the same bytes as libjpeg-turbo (checked against Pillow
+//                in tests/test_image_decode_cpu.py).  Arithmetic coding, lossless / hierarchical modes, 12-bit and CMYK
+//                files are refused with a message, never decoded approximately.
 //
 // Header-only, no dependency (own inflate).  Errors throw ImageError; nothing here touches the GPU.
 #ifndef MIRHI_IMAGE_DECODE_HPP
@@ -420,6 +422,7 @@ struct JBits {
         const int v = (int)(acc >> (32 - s)); drop(s);
         return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
     }
+    inline int bits(int k) { if (cnt < k) fill(); const int v = (int)(acc >> (32 - k)); drop(k); return v; }   // 1 <= k <= 16
     inline int decode(const JHuff& h) {
         if (cnt < 16) fill();
         const uint16_t e = h.look[acc >> 23];
@@ -505,6 +508,8 @@ struct JComp {
     uint32_t bw = 0, bh = 0;            // blocks per row / column (padded to whole MCUs)
     uint32_t cw = 0, chh = 0;           // real (downsampled) sample dimensions
     std::vector<uint8_t> plane;         // bw*8 x bh*8
+    std::vector<int16_t> coef;          // bw*bh blocks of 64 coefficients in natural order, accumulated over the scans
+    uint16_t q[64]; bool latched = false;   // the component's quantiser (natural order), fixed at its first scan
 };
 
 // triangle-filter 2x horizontal upsampling of one row of `n` samples into 2n
@@ -540,16 +545,17 @@ inline ImageData decode_jpeg(const uint8_t* p, size_t n) {
     static thread_local JHuff dc[4], ac[4];
     for (int i = 0; i < 4; i++) { dc[i].present = false; ac[i].present = false; }
     std::vector<JComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1; uint32_t restart = 0;
-    int adobe_transform = -1; bool have_sof = false, jfif = false;
+    int adobe_transform = -1; bool have_sof = false, jfif = false, progressive = false, saw_scan = false, saw_eoi = false;
+    uint32_t mcux = 0, mcuy = 0;
     size_t pos = 2;
-    for (;;) {
-        if (pos + 4 > n) throw ImageError("JPEG: no scan data before the end of the file");
+    while (!saw_eoi) {
+        if (pos + 2 > n) { if (saw_scan) break; throw ImageError("JPEG: no scan data before the end of the file"); }   // (a missing EOI is tolerated, as libjpeg does)
         if (p[pos] != 0xFF) throw ImageError("JPEG: expected a marker at byte " + std::to_string(pos));
         while (pos < n && p[pos] == 0xFF) pos++;            // fill bytes
-        if (pos >= n) throw ImageError("JPEG: truncated marker");
+        if (pos >= n) { if (saw_scan) break; throw ImageError("JPEG: truncated marker"); }
         const uint8_t m = p[pos++];
         if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (m == 0xD9) throw ImageError("JPEG: end of image before any scan");
+        if (m == 0xD9) { saw_eoi = true; break; }
         if (pos + 2 > n) throw ImageError("JPEG: truncated segment");
         const size_t len = be16(p + pos);
         if (len < 2 || pos + len > n) throw ImageError("JPEG: segment runs past the end of the file");
@@ -577,7 +583,7 @@ inline ImageData decode_jpeg(const uint8_t* p, size_t n) {
                 memset(h.vals, 0, sizeof h.vals); memcpy(h.vals, s + i, total); i += total;
                 h.build();
             }
-        } else if (m == 0xC0 || m == 0xC1) {                 // SOF0 / SOF1
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {    // SOF0 / SOF1 (sequential) / SOF2 (progressive)
             if (have_sof) throw ImageError("JPEG: more than one frame header");
             if (sl < 6) throw ImageError("JPEG: truncated frame header");
             if (s[0] != 8) throw ImageError("JPEG: " + std::to_string(s[0]) + "-bit samples are not supported (8-bit only)");
@@ -592,82 +598,168 @@ inline ImageData decode_jpeg(const uint8_t* p, size_t n) {
                 if (comps[c].h > hmax) hmax = comps[c].h;
                 if (comps[c].v > vmax) vmax = comps[c].v;
             }
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }     // a single-component image is never interleaved
+            progressive = m == 0xC2;
+            mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+            if ((uint64_t)mcux * mcuy * hmax * vmax * 64 * comps.size() > (1ull << 30)) throw ImageError("JPEG: image too large");
+            for (auto& c : comps) {
+                c.bw = mcux * c.h; c.bh = mcuy * c.v;
+                c.cw = (uint32_t)(((uint64_t)W * c.h + hmax - 1) / hmax); c.chh = (uint32_t)(((uint64_t)H * c.v + vmax - 1) / vmax);
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+            }
             have_sof = true;
-        } else if (m == 0xC2) throw ImageError("JPEG: progressive files are not supported (baseline / extended sequential only)");
-        else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) throw ImageError("JPEG: lossless / hierarchical / arithmetic-coded files are not supported");
+        } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) throw ImageError("JPEG: lossless / hierarchical / arithmetic-coded files are not supported");
         else if (m == 0xCC) throw ImageError("JPEG: arithmetic coding is not supported");
         else if (m == 0xDD) { if (sl < 2) throw ImageError("JPEG: truncated DRI"); restart = be16(s); }
         else if (m == 0xE0) { if (sl >= 5 && memcmp(s, "JFIF\0", 5) == 0) jfif = true; }
         else if (m == 0xEE) { if (sl >= 12 && memcmp(s, "Adobe", 5) == 0) adobe_transform = s[11]; }
-        else if (m == 0xDA) {                                // SOS: the single scan of a sequential file
+        else if (m == 0xDA) {                                // SOS: one scan (the only one of a baseline file; one of many otherwise)
             if (!have_sof) throw ImageError("JPEG: scan before frame header");
             const int ns = sl ? s[0] : 0;
-            if (ns != (int)comps.size()) throw ImageError("JPEG: non-interleaved multi-scan sequential files are not supported");
+            if (ns < 1 || ns > (int)comps.size()) throw ImageError("JPEG: bad component count in scan header");
             if (sl < (size_t)1 + 2 * ns + 3) throw ImageError("JPEG: truncated scan header");
+            JComp* sc[3];
             for (int k = 0; k < ns; k++) {
-                const int cid = s[1 + 2 * k]; bool found = false;
-                for (auto& c : comps) if (c.id == cid) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; found = true; }
-                if (!found) throw ImageError("JPEG: scan names an unknown component");
-                if (comps[k].id != cid) throw ImageError("JPEG: scan component order differs from the frame header");
+                const int cid = s[1 + 2 * k]; sc[k] = nullptr;
+                for (auto& c : comps) if (c.id == cid) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; sc[k] = &c; }
+                if (!sc[k]) throw ImageError("JPEG: scan names an unknown component");
+                for (int j = 0; j < k; j++) if (sc[j] == sc[k]) throw ImageError("JPEG: scan names a component twice");
+                if (sc[k]->td > 3 || sc[k]->ta > 3) throw ImageError("JPEG: bad Huffman table selector");
+                if (!sc[k]->latched) {                       // the quantiser in force at a component's first scan is the one it keeps
+                    if (!have_qt[sc[k]->tq]) throw ImageError("JPEG: component uses an undefined quantisation table");
+                    memcpy(sc[k]->q, qt[sc[k]->tq], sizeof sc[k]->q); sc[k]->latched = true;
+                }
             }
-            pos += len;
-            break;
+            const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+            if (!progressive) { if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) throw ImageError("JPEG: bad spectral selection in a sequential scan"); }
+            else if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13 || Ah > 13) throw ImageError("JPEG: bad progressive scan parameters");
+            const bool need_dc = Ss == 0 && Ah == 0, need_ac = Se > 0;
+            for (int k = 0; k < ns; k++) {
+                if (need_dc && !dc[sc[k]->td].present) throw ImageError("JPEG: scan uses an undefined DC Huffman table");
+                if (need_ac && !ac[sc[k]->ta].present) throw ImageError("JPEG: scan uses an undefined AC Huffman table");
+                sc[k]->pred = 0;
+            }
+            JBits br(p, n, pos + len);
+            // a scan of one component is not interleaved: its blocks run in raster order over the component's own size
+            const uint32_t bx_n = ns == 1 ? (sc[0]->cw + 7) / 8 : mcux, by_n = ns == 1 ? (sc[0]->chh + 7) / 8 : mcuy;
+            uint32_t until_restart = restart, eobrun = 0; int next_rst = 0;
+            for (uint32_t my = 0; my < by_n; my++) for (uint32_t mx = 0; mx < bx_n; mx++) {
+                if (restart && until_restart == 0) {
+                    br.reset();                              // byte-align, expect RSTn
+                    size_t q = br.pos;
+                    while (q + 1 < n && !(p[q] == 0xFF && p[q + 1] >= 0xD0 && p[q + 1] <= 0xD7)) {
+                        if (p[q] == 0xFF && p[q + 1] != 0 && p[q + 1] != 0xFF) throw ImageError("JPEG: expected a restart marker");
+                        q++;
+                    }
+                    if (q + 1 >= n) throw ImageError("JPEG: missing restart marker");
+                    if ((p[q + 1] & 7) != next_rst) throw ImageError("JPEG: restart markers out of order");
+                    next_rst = (next_rst + 1) & 7;
+                    br.pos = q + 2;
+                    for (int k = 0; k < ns; k++) sc[k]->pred = 0;
+                    eobrun = 0;
+                    until_restart = restart;
+                }
+                for (int k = 0; k < ns; k++) {
+                    JComp& c = *sc[k];
+                    const int nh = ns == 1 ? 1 : c.h, nv = ns == 1 ? 1 : c.v;
+                    for (int by = 0; by < nv; by++) for (int bx = 0; bx < nh; bx++) {
+                        int16_t* blk = c.coef.data() + ((size_t)(my * nv + by) * c.bw + (size_t)(mx * nh + bx)) * 64;
+                        if (!progressive) {
+                            const int t = br.decode(dc[c.td]);
+                            if (t > 11) throw ImageError("JPEG: bad DC difference size");
+                            c.pred += br.receive_extend(t);
+                            if (c.pred > 32767 || c.pred < -32768) throw ImageError("JPEG: DC predictor out of range");
+                            blk[0] = (int16_t)c.pred;
+                            for (int kk = 1; kk < 64;) {
+                                const int rs = br.decode(ac[c.ta]); const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) { if (r == 15) { kk += 16; continue; } break; }
+                                kk += r;
+                                if (kk > 63) throw ImageError("JPEG: AC coefficient index out of range");
+                                blk[ZIGZAG[kk]] = (int16_t)br.receive_extend(sz);
+                                kk++;
+                            }
+                        } else if (Ss == 0) {
+                            if (Ah == 0) {                   // DC, first pass
+                                const int t = br.decode(dc[c.td]);
+                                if (t > 11) throw ImageError("JPEG: bad DC difference size");
+                                c.pred += br.receive_extend(t);
+                                if (c.pred > 32767 || c.pred < -32768) throw ImageError("JPEG: DC predictor out of range");
+                                blk[0] = (int16_t)((uint16_t)c.pred << Al);
+                            } else if (br.bits(1)) blk[0] = (int16_t)(blk[0] | (1 << Al));       // DC, refinement bit
+                        } else if (Ah == 0) {                // AC band, first pass (T.81 G.1.2.2)
+                            if (eobrun) { eobrun--; continue; }
+                            for (int kk = Ss; kk <= Se;) {
+                                const int rs = br.decode(ac[c.ta]); const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r < 15) { eobrun = (1u << r) - 1u + (r ? (uint32_t)br.bits(r) : 0u); break; }
+                                    kk += 16; continue;
+                                }
+                                kk += r;
+                                if (kk > Se) throw ImageError("JPEG: AC coefficient index out of range");
+                                blk[ZIGZAG[kk]] = (int16_t)(br.receive_extend(sz) * (1 << Al));
+                                kk++;
+                            }
+                        } else {                             // AC band, refinement (T.81 G.1.2.3)
+                            const int p1 = 1 << Al, m1 = -(1 << Al);
+                            int kk = Ss;
+                            if (!eobrun) {
+                                for (; kk <= Se; kk++) {
+                                    const int rs = br.decode(ac[c.ta]); int r = rs >> 4; const int sz = rs & 15; int val = 0;
+                                    if (sz) {
+                                        if (sz != 1) throw ImageError("JPEG: corrupt refinement scan");
+                                        val = br.bits(1) ? p1 : m1;
+                                    } else if (r != 15) {
+                                        eobrun = 1u << r;
+                                        if (r) eobrun += (uint32_t)br.bits(r);
+                                        break;
+                                    }
+                                    // skip r still-zero coefficients, handing correction bits to the nonzero ones on the way
+                                    for (; kk <= Se; kk++) {
+                                        int16_t& cf = blk[ZIGZAG[kk]];
+                                        if (cf != 0) {
+                                            if (br.bits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                        } else if (--r < 0) break;
+                                    }
+                                    if (val && kk <= Se) blk[ZIGZAG[kk]] = (int16_t)val;
+                                }
+                            }
+                            if (eobrun) {                    // the rest of the band: correction bits only
+                                for (; kk <= Se; kk++) {
+                                    int16_t& cf = blk[ZIGZAG[kk]];
+                                    if (cf != 0 && br.bits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                }
+                                eobrun--;
+                            }
+                        }
+                    }
+                }
+                if (restart) until_restart--;
+            }
+            // the next marker: the reader stopped at it or just before it (padding bits); restart markers belong to the scan
+            size_t q = br.pos;
+            while (q + 1 < n && !(p[q] == 0xFF && p[q + 1] != 0x00 && p[q + 1] != 0xFF && !(p[q + 1] >= 0xD0 && p[q + 1] <= 0xD7))) q++;
+            pos = q + 1 < n ? q : n;
+            saw_scan = true;
+            if (!progressive && ns == (int)comps.size()) { /* the usual single interleaved scan: nothing else can follow but EOI */ }
+            continue;
         }
         pos += len;
     }
-    for (auto& c : comps) {
-        if (!have_qt[c.tq]) throw ImageError("JPEG: component uses an undefined quantisation table");
-        if (c.td > 3 || c.ta > 3 || !dc[c.td].present || !ac[c.ta].present) throw ImageError("JPEG: component uses an undefined Huffman table");
-    }
-    if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }     // a single-component scan is never interleaved
-    const uint32_t mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-    if ((uint64_t)mcux * mcuy * hmax * vmax * 64 * comps.size() > (1ull << 31)) throw ImageError("JPEG: image too large");
-    for (auto& c : comps) {
-        c.bw = mcux * c.h; c.bh = mcuy * c.v;
-        c.cw = (uint32_t)(((uint64_t)W * c.h + hmax - 1) / hmax); c.chh = (uint32_t)(((uint64_t)H * c.v + vmax - 1) / vmax);
-        c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0); c.pred = 0;
-    }
-    JBits br(p, n, pos);
-    uint32_t until_restart = restart; int next_rst = 0;
-    int32_t blk[64];
-    for (uint32_t my = 0; my < mcuy; my++) for (uint32_t mx = 0; mx < mcux; mx++) {
-        if (restart && until_restart == 0) {
-            // byte-align, expect RSTn
-            br.reset();
-            size_t q = br.pos;
-            while (q + 1 < n && !(p[q] == 0xFF && p[q + 1] >= 0xD0 && p[q + 1] <= 0xD7)) {
-                if (p[q] == 0xFF && p[q + 1] != 0 && p[q + 1] != 0xFF) throw ImageError("JPEG: expected a restart marker");
-                q++;
-            }
-            if (q + 1 >= n) throw ImageError("JPEG: missing restart marker");
-            if ((p[q + 1] & 7) != next_rst) throw ImageError("JPEG: restart markers out of order");
-            next_rst = (next_rst + 1) & 7;
-            br.pos = q + 2;
-            for (auto& c : comps) c.pred = 0;
-            until_restart = restart;
-        }
+    if (!saw_scan) throw ImageError("JPEG: no scan in the file");
+    for (auto& c : comps) if (!c.latched) throw ImageError("JPEG: a component has no scan");
+    // dequantise + inverse DCT, block by block
+    {
+        int32_t blk[64];
         for (auto& c : comps) {
-            const uint16_t* q = qt[c.tq];
-            for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
-                memset(blk, 0, sizeof blk);
-                const int t = br.decode(dc[c.td]);
-                if (t > 11) throw ImageError("JPEG: bad DC difference size");
-                c.pred += br.receive_extend(t);
-                if (c.pred > (1 << 20) || c.pred < -(1 << 20)) throw ImageError("JPEG: DC predictor out of range");
-                blk[0] = dequant(c.pred, q[0]);
-                for (int k = 1; k < 64;) {
-                    const int rs = br.decode(ac[c.ta]); const int r = rs >> 4, sz = rs & 15;
-                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                    k += r;
-                    if (k > 63) throw ImageError("JPEG: AC coefficient index out of range");
-                    blk[ZIGZAG[k]] = dequant(br.receive_extend(sz), q[ZIGZAG[k]]);
-                    k++;
-                }
-                const size_t stride = (size_t)c.bw * 8;
-                idct8x8(blk, c.plane.data() + ((size_t)(my * c.v + by) * 8) * stride + (size_t)(mx * c.h + bx) * 8, stride);
+            c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+            const size_t stride = (size_t)c.bw * 8;
+            for (uint32_t by = 0; by < c.bh; by++) for (uint32_t bx = 0; bx < c.bw; bx++) {
+                const int16_t* src = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                for (int k = 0; k < 64; k++) blk[k] = dequant(src[k], c.q[k]);
+                idct8x8(blk, c.plane.data() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
             }
+            std::vector<int16_t>().swap(c.coef);
         }
-        if (restart) until_restart--;
     }
 
     ImageData out; out.width = W; out.height = H; out.source_channels = (uint32_t)comps.size();

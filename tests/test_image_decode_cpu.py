@@ -4,7 +4,7 @@ No GPU.  Expected pixels come from two independent sources:
   * PNG: files are ENCODED here by a small writer (zlib + struct) that exercises every colour type, bit depth, all five
     scanline filters and Adam7, with the expected RGBA computed in numpy straight from the PNG specification's sample
     scaling rules (16 -> 8 bit by the `image` crate's (c + 128) / 257); Pillow is a second opinion where it has the mode.
-  * JPEG: files are encoded by Pillow (libjpeg-turbo) with different sampling, quality, restart and Huffman options and
+  * JPEG: files are encoded by Pillow (libjpeg-turbo), sequential and progressive, with different sampling, quality, restart and Huffman options and
     decoded by Pillow again; the decoder here restates the same integer IDCT / colour conversion / triangle upsampling,
     so the comparison is bit for bit, not a tolerance.
 """
@@ -266,6 +266,31 @@ def test_jpeg_restart_intervals(subsampling, blocks):
     assert np.array_equal(images.decode_image(data).rgba, ref)
 
 
+@pytest.mark.parametrize("size", [(1, 1), (8, 8), (17, 9), (33, 47), (130, 70)])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("quality", [30, 92])
+def test_jpeg_progressive_matches_libjpeg_bit_for_bit(size, subsampling, quality):
+    """SOF2: DC first / refinement scans, AC band first passes with end-of-band runs, AC refinement with correction bits
+    (libjpeg's default progression script: 10 scans for a colour image)"""
+    rng = np.random.default_rng(hash((size, subsampling, quality, 1)) & 0xFFFFFFFF)
+    w, h = size
+    data, ref = _jpeg(_photo(h, w, rng), "RGB", quality=quality, subsampling=subsampling, progressive=True)
+    assert b"\xff\xc2" in data and data.count(b"\xff\xda") > 5
+    got = images.decode_image(data)
+    assert np.array_equal(got.rgba, ref), f"max diff {np.abs(got.rgba.astype(int) - ref.astype(int)).max()}"
+
+
+def test_jpeg_progressive_greyscale_and_restarts():
+    rng = np.random.default_rng(8)
+    data, ref = _jpeg(_photo(45, 61, rng, 1)[..., 0], "L", quality=75, progressive=True)
+    assert np.array_equal(images.decode_image(data).rgba, ref)
+    data, ref = _jpeg(_photo(75, 100, rng), "RGB", quality=85, subsampling=2, progressive=True, restart_marker_blocks=2)
+    assert b"\xff\xdd" in data
+    assert np.array_equal(images.decode_image(data).rgba, ref)
+    data, ref = _jpeg(_photo(64, 64, rng), "RGB", quality=100, subsampling=0, progressive=True, optimize=True)
+    assert np.array_equal(images.decode_image(data).rgba, ref)
+
+
 def test_jpeg_custom_quantisation_tables():
     rng = np.random.default_rng(3)
     qt = [[min(255, 1 + 3 * i) for i in range(64)], [min(255, 2 + 5 * i) for i in range(64)]]
@@ -275,9 +300,6 @@ def test_jpeg_custom_quantisation_tables():
 
 def test_jpeg_unsupported_variants_are_refused():
     rng = np.random.default_rng(4)
-    data, _ = _jpeg(_photo(32, 32, rng), "RGB", progressive=True)
-    with pytest.raises(images.ImageDecodeError, match="progressive"):
-        images.decode_image(data)
     from PIL import Image
     buf = io.BytesIO()
     Image.fromarray(_photo(16, 16, rng, 4), "CMYK").save(buf, "JPEG")
@@ -298,7 +320,8 @@ def test_fuzzed_files_never_crash():
     rng = np.random.default_rng(11)
     png = _png_rgb(19, 13)
     jpg, _ = _jpeg(_photo(24, 40, rng), "RGB", subsampling=2)
-    for base in (png, jpg):
+    pjpg, _ = _jpeg(_photo(24, 40, rng), "RGB", subsampling=1, progressive=True)
+    for base in (png, jpg, pjpg):
         for _ in range(300):
             b = bytearray(base)
             for _ in range(int(rng.integers(1, 4))):
