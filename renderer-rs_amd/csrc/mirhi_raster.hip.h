@@ -219,18 +219,31 @@ __device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, u
     int32_t r0 = mad24(B0, by0, mad24(A0, bx0, (int32_t)rec[0].x));
     int32_t r1 = mad24(B1, by0, mad24(A1, bx0, (int32_t)rec[0].y));
     int32_t r2 = mad24(B2, by0, mad24(A2, bx0, (int32_t)rec[0].z));
+    // Two pixels per step: the two coverage tests / depth evaluations are independent instruction chains, which is what a
+    // wave that sits alone on its SIMD (a mesh's hot tiles while most of the chip is idle) needs to keep issuing.
+    const int32_t A0x2 = A0 + A0, A1x2 = A1 + A1, A2x2 = A2 + A2;
     for (int32_t iy = by0; iy <= by1; iy++) {
         int32_t s0 = r0, s1 = r1, s2 = r2;
         const float dy = (float)iy + dyt;
-        for (int32_t ix = bx0; ix <= bx1; ix++) {
-            if ((s0 | s1 | s2) >= 0) {
+        for (int32_t ix = bx0; ix <= bx1; ix += 2) {
+            const int32_t t0 = s0 + A0, t1 = s1 + A1, t2 = s2 + A2;
+            const bool in_a = (s0 | s1 | s2) >= 0;
+            const bool in_b = (t0 | t1 | t2) >= 0 && ix < bx1;
+            if (in_a) {
                 const float dx = (float)ix + dxt;
                 const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
                 uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
                 if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
                 atomicMin(&lds_key[iy * TILE + ix], ((unsigned long long)zk << 32) | idk);
             }
-            s0 += A0; s1 += A1; s2 += A2;
+            if (in_b) {
+                const float dx = (float)(ix + 1) + dxt;
+                const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+                uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+                if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
+                atomicMin(&lds_key[iy * TILE + ix + 1], ((unsigned long long)zk << 32) | idk);
+            }
+            s0 += A0x2; s1 += A1x2; s2 += A2x2;
         }
         r0 += B0; r1 += B1; r2 += B2;
     }
