@@ -948,6 +948,36 @@ static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
     else { P.init_zk = t - 1u; P.init_idk = NO_PRIM; }
 }
 
+// How a scope is rastered (decided once per recorded scope, used for sizing the workspace and for the launch):
+//  tp_max_area  triangle-parallel resolve of small records pays when tiles hold many triangles (meshes); sparse scopes keep
+//               the leaner pixel-parallel-only kernel.  Scopes of TRIANGLE-program draws switch at 16 triangles per tile on
+//               average (their variant gives up one wave of occupancy for the LDS key array); mesh-program scopes lose nothing
+//               and a mesh covers a fraction of the frame (the dancer asset: 8 per tile on average, 124 per tile it touches),
+//               so they switch at 4.  Box limit 64 pixels: measured against 96 / 128 on the dancer (74 / 81 / 89 us), C3
+//               (38.6 / 36.8 / 37.1), C4 (112.9 / 112.4 / 112.4) and C5 (202 / 206 / 211).
+//  teams        two teams per tile + per-XCD bins when a mesh scope is dense enough for the triangle-parallel variant yet
+//               averages under 16 triangles per tile: then its triangles sit in a small part of the frame (the dancer: 919 in
+//               the fullest tile), the chip is far from full, the raster kernel lasts as long as the fullest tile's serial
+//               chain -- which two teams cut (dancer raster 62.6 -> 44.0 us; four teams: 47.4) -- and the geometry kernel as
+//               long as the queue of atomics on the hottest bin counter, which per-XCD counters cut (see reserve_bin_slots).
+//  MIRHI_TP_MAX_AREA (0 = off), MIRHI_TP_DENSITY, MIRHI_RASTER_TEAMS (1 / 2) override for A/B measurements.
+struct RasterMode { uint32_t tp_max_area, teams; bool tri_prog; };
+static RasterMode raster_mode(const RecordedPass& pass, size_t tiles) {
+    RasterMode m{0u, 1u, false};
+    for (const DrawDesc& dd : pass.draws) m.tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
+    PassParams key{};
+    depth_key_setup(key, pass);
+    const size_t avg = tiles ? (pass.total_tris - pass.first_tri) / tiles : 0;
+    const size_t density = getenv("MIRHI_TP_DENSITY") ? (size_t)atoi(getenv("MIRHI_TP_DENSITY")) : (m.tri_prog ? 16 : 4);
+    const bool dense = tiles && avg >= density;
+    m.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 64u : 0u);
+    if (key.pred) m.tp_max_area = 0;      // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
+    const bool mesh_only = !m.tri_prog && !pass.draws.empty();
+    m.teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : (avg < 16 ? 2u : 1u);
+    if (!(m.tp_max_area && mesh_only && !pass_is_ordered(pass)) || m.teams != 2u) m.teams = 1u;
+    return m;
+}
+
 extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     REQUIRE_RECORDING(cmd);
     if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
@@ -976,7 +1006,9 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             if (floor_cap > pass.total_tris) floor_cap = pass.total_tris;
             if (cap < floor_cap) cap = floor_cap;
         }
-        cap = (cap + 63) & ~(size_t)63;
+        const RasterMode mode = raster_mode(pass, tiles);
+        if (mode.teams == 2u && cap < 2048) cap = 2048;       // eight per-XCD sub-bins of at least 256 records
+        cap = (cap + 511) & ~(size_t)511;                     // (a multiple of 8 x 64)
         if (cap > 4096) cap = 4096;
         g.bin_cap = (uint32_t)cap;
         g.big_cap = pass.total_tris + pass.total_tris / 4 + 1024;
@@ -994,7 +1026,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     if ((r = grow(&w.bin_recs, &w.bin_recs_bytes, max_bin_bytes ? max_bin_bytes : sizeof(TileRec))) != MIRHI_OK) return r;
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
     size_t counter_bytes = w.counters_words * 4;
-    const size_t want_words = max_tiles + 8;
+    const size_t want_words = 8 * max_tiles + 8;          // bin counters (one per tile, or one per tile and XCD), big-list counters
     const bool fresh = !(w.counters && counter_bytes >= want_words * 4);
     if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
     w.counters_words = counter_bytes / 4;
@@ -1005,7 +1037,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         HIP_TRY(hipHostGetDevicePointer((void**)&w.status_dev, w.status_host, 0));
     }
     w.status_host[0] = 0; w.status_host[1] = 0;
-    w.big_counts = w.counters + max_tiles;
+    w.big_counts = w.counters + 8 * max_tiles;
     w.parity = 0;
 
     // vertex pre-pass jobs: one per distinct (vertex range, camera, object, program class) of each scope
@@ -1127,26 +1159,13 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
             P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
-        {   // triangle-parallel resolve of small records pays when tiles hold many triangles (meshes); sparse scopes keep
-            // the leaner pixel-parallel-only kernel.  Scopes of TRIANGLE-program draws switch at 16 triangles per tile on
-            // average (their variant gives up one wave of occupancy for the LDS key array); mesh-program scopes lose nothing
-            // and a mesh covers a fraction of the frame (the dancer asset: 8 per tile on average, 124 per tile it touches),
-            // so they switch at 4.  Box limit 64 pixels: measured against 96 / 128 on the dancer (74 / 81 / 89 us), C3
-            // (38.6 / 36.8 / 37.1), C4 (112.9 / 112.4 / 112.4) and C5 (202 / 206 / 211).
-            // MIRHI_TP_MAX_AREA (0 = off) and MIRHI_TP_DENSITY override for A/B measurements.
-            const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-            bool tri_prog = false;
-            for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
-            const size_t density = getenv("MIRHI_TP_DENSITY") ? (size_t)atoi(getenv("MIRHI_TP_DENSITY")) : (tri_prog ? 16 : 4);
-            const bool dense = tiles && (pass.total_tris - pass.first_tri) / tiles >= density;
-            P.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 64u : 0u);
-            if (P.pred) P.tp_max_area = 0;    // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
-            // Two teams per tile when a mesh scope is dense enough for the triangle-parallel variant yet averages under 16
-            // triangles per tile: then its triangles sit in a small part of the frame (the dancer asset: 8 on average, 124
-            // per tile it touches, 919 in the fullest), the chip is far from full and the kernel's duration is the fullest
-            // tile's serial chain -- which two teams cut (dancer raster 62.6 -> 44.0 us; four teams: 47.4).  MIRHI_RASTER_TEAMS (1 / 2) overrides.
-            const size_t avg = tiles ? (pass.total_tris - pass.first_tri) / tiles : 0;
-            P.raster_teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : ((P.tp_max_area && !tri_prog && avg < 16) ? 2u : 1u);
+        {
+            const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0));
+            P.tp_max_area = mode.tp_max_area;
+            P.raster_teams = mode.teams;
+            const bool xcd_bins = mode.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
+            P.sub_cap = xcd_bins ? g.bin_cap / 8u : g.bin_cap;
+            P.count_stride = xcd_bins ? (uint32_t)max_tiles : 0u;
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();

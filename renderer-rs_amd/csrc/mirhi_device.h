@@ -123,6 +123,10 @@ struct PassParams {
                                       // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
     uint32_t raster_teams;            // 2: the mesh variant with two teams of four waves per tile (host-side choice, see raster_kernel)
+    // Per-XCD bins (only together with raster_teams == 2): a tile's bin is eight sub-bins of sub_cap records, one per XCD,
+    // each with its own counter (bin_count[xcd * count_stride + tile]), so that a hot tile's counter line stays in one
+    // XCD's L2 -- see reserve_bin_slots.  Off: count_stride = 0, sub_cap = bin_cap.
+    uint32_t sub_cap, count_stride;
     // ordered segments (blending; any depth state whose result depends on the order of all fragments): the geometry kernel
     // writes triangle t of the segment to ordered_recs[t] instead of binning it, the ordered kernel walks that array
     TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;
@@ -137,6 +141,7 @@ struct GeometryHead { const DrawDesc* draws; uint32_t num_draws; };
 struct RasterHead {
     uint32_t* bin_count; const TileRec* bin_recs; uint32_t* big_count;
     uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;
+    uint32_t sub_cap, count_stride;   // per-XCD bins (PassParams); read by the two-team variant only
 };
 
 }  // namespace mirhi

@@ -257,7 +257,13 @@ constexpr uint32_t PAIR_MAX = GEOM_THREADS * MAX_BIN_SPAN * MAX_BIN_SPAN;
 // lane's own add fetched (meaningful on reserving lanes) and in `who` the reserving lane | rank within its group << 8.
 // One atomic per group IN SEPARATE ROUNDS (the first design) made the compiler wait for each result before the next
 // add -- up to nine serial round trips per wave, 13 us of the dancer asset's 29 us geometry time.
-__device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uint32_t tile, uint32_t lane, uint64_t lt, uint32_t& who) {
+// Per-XCD bins (PassParams::count_stride != 0, scopes whose triangles sit in few tiles): the counter a wave adds to is its
+// XCD's own copy.  Measured (tools/microbench/atomic_contention.hip, 17k returning atomics on 232 addresses, the dancer's
+// pattern): 14.4 us when all eight XCDs share the counters, 4.9 us with one copy per XCD, 2.4 us without any sharing --
+// a contended line ping-pongs between the XCDs' L2s at ~190 ns per atomic.
+__device__ __forceinline__ uint32_t xcd_of_wave() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }   // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uint32_t tile, uint32_t lane, uint64_t lt, uint32_t& who, uint32_t xcd) {
     constexpr int GROUP_ROUNDS = 12, GROUP_MIN = 2;
     who = lane;
     uint32_t gsize = act ? 1u : 0u;
@@ -272,7 +278,7 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
         rem &= ~grp;
     }
     uint32_t raw = 0;
-    if (gsize) raw = atomicAdd(&P.bin_count[tile], gsize);
+    if (gsize) raw = atomicAdd(&P.bin_count[xcd * P.count_stride + tile], gsize);
     return raw;
 }
 template <uint32_t BATCH>
@@ -280,6 +286,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                                                    uint32_t* lds_meta, uint16_t* lds_owner) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t xcd = P.count_stride ? xcd_of_wave() : 0u;        // wave-uniform
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
     bool spill = false;
     if (valid) {
@@ -296,10 +303,10 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         const uint32_t tile = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
         const bool act = nb == 1u;
         uint32_t who;
-        const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who);
+        const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who, xcd);
         const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
         if (act) {
-            if (slot < P.bin_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u, t);
+            if (slot < P.sub_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + xcd * P.sub_cap + slot) * 3u, t);
             else spill = true;       // bin full: the triangle goes to the big list
         }
         if (valid && spill) emit_big(P, t);
@@ -345,7 +352,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                 const uint32_t o = lds_owner[p], kk = o >> 8;
                 tile = (lds_meta[o & 0xFFu] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
             }
-            raw[k] = reserve_bin_slots(P, act, tile, lane, lt, who[k]);
+            raw[k] = reserve_bin_slots(P, act, tile, lane, lt, who[k], xcd);
         }
 #pragma unroll
         for (uint32_t k = 0; k < BATCH; k++) {
@@ -355,8 +362,8 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             if (p < total) {
                 const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
                 const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
-                if (slot < P.bin_cap) {
-                    uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + slot) * 3u;
+                if (slot < P.sub_cap) {
+                    uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + xcd * P.sub_cap + slot) * 3u;
                     dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
                 } else {
                     atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once

@@ -269,8 +269,10 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // TEAMS > 1 (mesh variants): the workgroup is TEAMS sets of four waves; team t stages and rasters chunks t, t + TEAMS, ...
 // of the list into its own staging area and its own register keys (tid = lane index within the team).  Every team runs
 // the same number of passes -- the barriers are workgroup-wide -- a team whose chunk lies beyond the list stages nothing.
+// seg (two-team variant, bin list only): the bin is eight per-XCD sub-bins of sub_cap records; seg[k] = records in the
+// sub-bins before k, so that flat index i lives in sub-bin #{k >= 1 : i >= seg[k]} at offset i - seg[that].  nullptr: a plain list.
 template <int KEYED, int TP, int CHUNK, int TEAMS>
-__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint4* lds_rec, uint32_t* lds_box,
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, const uint32_t* seg, uint32_t sub_cap, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
@@ -298,7 +300,14 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         if (ftid < (uint32_t)CHUNK && i < n_total) {
             // all three words are requested together: one memory round trip, not two (a bin holds only records whose
             // box overlaps the tile, so the box test below almost never saves the first two loads)
-            const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
+            size_t ri = i;
+            if (TEAMS > 1 && seg) {
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t j = 1; j < 8u; j++) k += i >= seg[j] ? 1u : 0u;
+                ri = (size_t)k * sub_cap + (i - seg[k]);
+            }
+            const uint4 w0 = list[ri * 3u], w1 = list[ri * 3u + 1u], w2 = list[ri * 3u + 2u];
             const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
             const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
             hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
@@ -387,8 +396,25 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     STAMP(0);
     // both counters are fetched up front so their latencies overlap
     // (the head of the parameters comes by value: the counter loads depend on the kernarg load alone, not on a second hop)
-    const uint32_t count_raw = H.bin_count[tile];
+    __shared__ uint32_t lds_seg[TEAMS > 1 ? 9 : 1];     // two-team variant: records in the per-XCD sub-bins before k; [8] = all
+    const bool xcd_bins = TEAMS > 1 && H.count_stride != 0u;
+    uint32_t count_raw = H.bin_count[tile];
     const uint32_t nbig_raw = *H.big_count;
+    if (TEAMS > 1) {
+        if (xcd_bins) {
+            if (threadIdx.x == 0) {
+                uint32_t c[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) c[k] = H.bin_count[k * H.count_stride + tile];
+                uint32_t acc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) { lds_seg[k] = acc; acc += c[k] < H.sub_cap ? c[k] : H.sub_cap; }
+                lds_seg[8] = acc;
+            }
+            __syncthreads();
+            count_raw = lds_seg[8];
+        }
+    }
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
     // (Letting the second team leave tiles whose lists fit one staging pass was measured: the scopes that get this variant
@@ -435,11 +461,14 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     uint32_t n_list = count;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, (xcd_bins && pass == 0) ? lds_seg : nullptr, H.sub_cap, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
-            if (count && tid == 0 && team == 0) H.bin_count[tile] = 0;   // ready for the next scope that uses this workspace
+            if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
+                H.bin_count[tile] = 0;
+                if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[k * H.count_stride + tile] = 0;
+            }
             if (!nbig) break;
             // parameters of this phase are (re)read here, see launder_params
             list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);

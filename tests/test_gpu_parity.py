@@ -169,6 +169,39 @@ def test_gltf_dancer_two_team_variant_states(mirhi, oracle, device, scenes, vari
     _check(out, ref, f"{scene.name}-{variant}", depth=True)
 
 
+def test_mesh_heap_overflows_the_per_xcd_bins(mirhi, oracle, device, scenes):
+    """20,000 lit triangles heaped into a 2x2-tile corner of a 1080p frame: on average under 16 per tile, so the scope gets
+    the concentrated-mesh mode (two teams per tile, one sub-bin of 256 records per XCD and tile) -- and every sub-bin of
+    those tiles overflows into the big list.  The frame must still be the oracle's."""
+    rng = np.random.default_rng(77)
+    nt = 20000
+    c = rng.uniform(0.005, 0.045, (nt, 1, 2))
+    p = c + rng.normal(0, 0.006, (nt, 3, 2))
+    z = rng.uniform(0.1, 0.9, (nt, 3, 1))
+    pos = np.concatenate([p, z], axis=2).reshape(nt * 3, 3)
+    nrm = rng.normal(0, 1, (nt * 3, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tan = np.tile(np.float32([1, 0, 0, 1]), (nt * 3, 1))
+    verts = scenes._pack_vertex48(pos, nrm, rng.uniform(0, 1, (nt * 3, 2)), tan)
+    eye4 = np.eye(4, dtype=np.float32)
+    d = scenes.DrawSpec(vertices=verts, stride=48, count=nt * 3, indices=np.arange(nt * 3, dtype=np.uint32),
+                        program=scenes.PROGRAM_MODEL_FULL, cull_mode=scenes.CULL_NONE,
+                        camera=scenes.camera_ubo(eye4, eye4, (0.0, 0.0, 3.0)), object=scenes.object_ubo(eye4),
+                        light=scenes.light_ubo(direction=(0.3, -1.0, 0.2), intensity=1.5, num_point=1),
+                        material=scenes.material_ubo((0.8, 0.6, 0.4, 1.0), 0.0, 0.4, 1.0),
+                        point_lights=scenes.point_light((0.5, 0.5, 2.0), 10.0, (1.0, 1.0, 1.0), 3.0),
+                        albedo_map=scenes.WHITE_1X1, normal_map=scenes.WHITE_1X1)
+    scene = scenes.Scene("mesh-heap", 1920, 1080, [d], clear_color=(0.1, 0.1, 0.15, 1.0))
+    res = mirhi.SceneResources(device, scene, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True, want_depth=True)
+    fence = mirhi.Fence(device)
+    res.render(); res.render(fence); fence.wait()
+    out = res.read()
+    big = device.stats().last_big_list
+    fence.destroy(); res.destroy()
+    assert big > 1000, f"expected the sub-bins to overflow into the big list, got {big} entries"
+    ref = oracle.render(scene, want_bgra8=True)
+    _check(out, ref, scene.name, depth=True)
+
+
 def test_submission_order_does_not_change_depth(mirhi, device, scenes):
     """Size-independent property at BASELINE configs[1] size: with LESS and distinct depths the stored depth image is a
     function of the triangle SET; reversing the submission order must leave it bit-identical (and permute prim ids)."""
