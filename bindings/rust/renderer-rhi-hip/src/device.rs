@@ -1,0 +1,69 @@
+//! crates/rhi/src/device.rs:61-380.  `Device::new` stands in for Instance + physical-device selection + logical device.
+use crate::error::{check, RhiResult};
+use std::sync::Arc;
+
+pub struct Device {
+    pub(crate) raw: *mut mirhi_sys::mirhi_device,
+}
+// device.rs:379-380: the reference's Device is Send + Sync; libmirhi guards its per-device state with a mutex
+unsafe impl Send for Device {}
+unsafe impl Sync for Device {}
+
+#[derive(Clone, Copy, Debug, Default)]
+pub struct DeviceStats {
+    pub frames_submitted: u64,
+    pub triangles_submitted: u64,
+    pub workspace_bytes: u64,
+    pub last_big_list: u32,
+    pub last_status: u32,
+}
+
+impl Device {
+    /// `hip_ordinal`: the GPU this process owns (one process per GPU; LOCAL_RANK under torchrun-style launchers).
+    pub fn new(hip_ordinal: i32) -> RhiResult<Arc<Self>> {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { mirhi_sys::mirhi_device_create(hip_ordinal, &mut raw) })?;
+        Ok(Arc::new(Self { raw }))
+    }
+    pub fn count() -> RhiResult<i32> {
+        let mut n = 0;
+        check(unsafe { mirhi_sys::mirhi_device_count(&mut n) })?;
+        Ok(n)
+    }
+    pub fn wait_idle(&self) -> RhiResult<()> {                       // device.rs:290-293
+        check(unsafe { mirhi_sys::mirhi_device_wait_idle(self.raw) })
+    }
+    pub fn name(&self) -> String {
+        let mut buf = [0 as std::os::raw::c_char; 256];
+        unsafe { mirhi_sys::mirhi_device_name(self.raw, buf.as_mut_ptr(), buf.len() as u32) };
+        unsafe { std::ffi::CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
+    }
+    /// Frames in flight run on separate HIP streams ("queue lanes"); frame_manager.rs's MAX_FRAMES_IN_FLIGHT goes here.
+    pub fn set_queue_lanes(&self, lanes: u32) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_device_set_queue_lanes(self.raw, lanes) })
+    }
+    /// Screen-tile-row split across the GPUs of a node: this process rasters band `rank` of `world`.
+    pub fn set_tile_split(&self, rank: u32, world: u32) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_device_set_tile_split(self.raw, rank, world) })
+    }
+    /// Submit recorded command buffers in order; semaphores of `vkQueueSubmit` collapse to stream order (renderer.rs:407-424).
+    pub fn submit(&self, cmds: &[&crate::CommandBuffer], fence: Option<&crate::Fence>) -> RhiResult<()> {
+        let raws: Vec<*mut mirhi_sys::mirhi_cmd> = cmds.iter().map(|c| c.raw).collect();
+        let f = fence.map_or(std::ptr::null_mut(), |f| f.raw);
+        check(unsafe { mirhi_sys::mirhi_queue_submit(self.raw, raws.len() as u32, raws.as_ptr(), f) })
+    }
+    pub fn stats(&self) -> RhiResult<DeviceStats> {
+        let mut s = std::mem::MaybeUninit::<mirhi_sys::mirhi_device_stats>::zeroed();
+        check(unsafe { mirhi_sys::mirhi_device_get_stats(self.raw, s.as_mut_ptr()) })?;
+        let s = unsafe { s.assume_init() };
+        Ok(DeviceStats { frames_submitted: s.frames_submitted, triangles_submitted: s.triangles_submitted,
+                         workspace_bytes: s.workspace_bytes, last_big_list: s.last_big_list, last_status: s.last_status })
+    }
+}
+
+impl Drop for Device {
+    fn drop(&mut self) {
+        // children hold an Arc<Device>, so none is alive here (the C side would refuse otherwise: "device still has N live child objects")
+        unsafe { mirhi_sys::mirhi_device_destroy(self.raw) };
+    }
+}

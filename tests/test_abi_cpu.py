@@ -120,3 +120,33 @@ def test_generated_rust_sys_crate_covers_the_header():
         for k, v in items:
             assert f"pub const {k}: {e} = {v};" in text
     assert "pub const MIRHI_ERR_PIPELINE: mirhi_result = 9;" in text
+
+
+def test_rust_wrapper_crate_only_uses_what_the_sys_crate_declares():
+    """bindings/rust/renderer-rhi-hip (the safe wrappers with the rhi names; not compiled here -- no Rust toolchain) must stay
+    in step with the generated mirhi-sys crate: every function, constant, struct and struct field it names exists there."""
+    import glob
+    sys_src = open(os.path.join(ROOT, "bindings", "rust", "mirhi-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub fn (mirhi_\w+)", sys_src)) | set(re.findall(r"pub const (MIRHI_\w+)", sys_src)) \
+        | set(re.findall(r"pub struct (mirhi_\w+)", sys_src)) | set(re.findall(r"pub type (mirhi_\w+)", sys_src))
+    fields = {}
+    for name, body in re.findall(r"pub struct (mirhi_\w+) \{\n(.*?)\n\}", sys_src, re.S):
+        fields[name] = set(re.findall(r"pub (\w+):", body))
+    files = sorted(glob.glob(os.path.join(ROOT, "bindings", "rust", "renderer-rhi-hip", "src", "*.rs")))
+    assert len(files) >= 8
+    used = set()
+    for f in files:
+        src = open(f).read()
+        used |= set(re.findall(r"mirhi_sys::(mirhi_\w+|MIRHI_\w+)", src))
+        if "use mirhi_sys::*;" in src:
+            used |= set(re.findall(r"\b(MIRHI_[A-Z_]+)\b", src))
+        assert src.count("{") == src.count("}") and src.count("(") == src.count(")"), f"unbalanced delimiters in {f}"
+    missing = sorted(u for u in used if u not in declared)
+    assert not missing, f"renderer-rhi-hip names symbols mirhi-sys does not declare: {missing}"
+    assert len(used) > 60
+    pipe = open(os.path.join(ROOT, "bindings", "rust", "renderer-rhi-hip", "src", "pipeline.rs")).read()
+    for fld in set(re.findall(r"self\.desc\.(\w+)", pipe)):
+        assert fld in fields["mirhi_pipeline_desc"], fld
+    cmd = open(os.path.join(ROOT, "bindings", "rust", "renderer-rhi-hip", "src", "command.rs")).read()
+    for fld in set(re.findall(r"\bri\.(\w+) =", cmd)):
+        assert fld in fields["mirhi_rendering_info"], fld
