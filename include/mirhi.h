@@ -62,7 +62,8 @@ mirhi_result mirhi_device_count(int32_t* out_count);                      /* phy
 mirhi_result mirhi_device_create(int32_t hip_ordinal, mirhi_device** out);
 /* same, but all work is issued on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
 mirhi_result mirhi_device_create_on_stream(int32_t hip_ordinal, void* hip_stream, mirhi_device** out);
-mirhi_result mirhi_device_wait_idle(mirhi_device* dev);
+mirhi_result mirhi_device_wait_idle(mirhi_device* dev);                   /* Device::wait_idle :290-293; also reports (once) the device-side
+                                                                             status of frames submitted without a fence, as mirhi_fence_wait does */
 mirhi_result mirhi_device_destroy(mirhi_device* dev);                     /* fails if children are alive */
 mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t out_len);
 /* screen-tile-row split: this device rasterizes only tile rows owned by `rank` of `world`

@@ -6,6 +6,7 @@
 // frame_manager.rs:299-539).  No rasterization arithmetic lives here and there is no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -90,6 +91,7 @@ struct mirhi_device {
     bool profiling = false;
     std::mutex mu;
     std::vector<EventPair> pending[MIRHI_KERNEL_COUNT];
+    std::vector<mirhi_cmd*> unchecked;        // submitted since the last wait_idle: their status words are read there
     std::vector<EventPair> pending_empty;     // one EMPTY pair per profiled scope, recorded right behind the raster pair
     std::vector<EventPair> free_events;
     double event_overhead_ms = 0.0;          // calibrated duration of an EMPTY hipEvent pair on the submit stream
@@ -255,9 +257,12 @@ static mirhi_result sync_all_lanes(mirhi_device* dev) {
     for (hipStream_t st : dev->lanes) HIP_TRY(hipStreamSynchronize(st));
     return MIRHI_OK;
 }
+static mirhi_result check_status_words(mirhi_device* dev);
 extern "C" mirhi_result mirhi_device_wait_idle(mirhi_device* dev) {
     NULL_CHECK(dev, "device");
-    return sync_all_lanes(dev);
+    mirhi_result r = sync_all_lanes(dev);
+    if (r != MIRHI_OK) return r;
+    return check_status_words(dev);         // a frame that went wrong on the device fails here too, not only at a fence
 }
 extern "C" mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t lanes) {
     NULL_CHECK(dev, "device");
@@ -642,6 +647,11 @@ extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
 extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
     (void)sync_all_lanes(cmd->dev);
+    {
+        std::lock_guard<std::mutex> lock(cmd->dev->mu);
+        auto& u = cmd->dev->unchecked;
+        u.erase(std::remove(u.begin(), u.end(), cmd), u.end());
+    }
     free_workspace(cmd);
     cmd->dev->children--;
     delete cmd;
@@ -1237,6 +1247,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     for (uint32_t i = 0; i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
+        if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
             const PassParams& P = c->plan[pi];
             // alternate the big-list counter: the raster kernel zeroes the other one for the next scope
@@ -1293,17 +1304,35 @@ extern "C" mirhi_result mirhi_fence_create(mirhi_device* dev, uint32_t signaled,
     *out = f;
     return MIRHI_OK;
 }
+// device-side status of one finished command buffer -> stats + error (the same text whether a fence or wait_idle finds it)
+static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
+    mirhi_result r = MIRHI_OK;
+    if (c->ws.status_host) {
+        dev->stats.last_status = c->ws.status_host[0];
+        dev->stats.last_big_list = c->ws.status_host[1];
+        if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
+            r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: MODEL_PBR alpha cutoff together with a base colour texture (per-fragment discard); that draw was skipped");
+        if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)
+            r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer large-triangle list overflowed (%u entries); frame is incomplete", c->ws.status_host[1]);
+    }
+    return r;
+}
+static mirhi_result check_status_words(mirhi_device* dev) {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    mirhi_result r = MIRHI_OK;
+    for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
+    dev->unchecked.clear();
+    return r;
+}
 static mirhi_result fence_complete(mirhi_fence* f) {
     f->pending = false; f->signaled = true;
     mirhi_result r = MIRHI_OK;
-    for (mirhi_cmd* c : f->cmds) {
-        if (c->ws.status_host) {
-            f->dev->stats.last_status = c->ws.status_host[0];
-            f->dev->stats.last_big_list = c->ws.status_host[1];
-            if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
-                r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: MODEL_PBR alpha cutoff together with a base colour texture (per-fragment discard); that draw was skipped");
-            if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)
-                r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer large-triangle list overflowed (%u entries); frame is incomplete", c->ws.status_host[1]);
+    {
+        std::lock_guard<std::mutex> lock(f->dev->mu);          // what a fence has reported is not reported again by wait_idle
+        for (mirhi_cmd* c : f->cmds) {
+            const mirhi_result rc = status_of(f->dev, c); if (rc != MIRHI_OK) r = rc;
+            auto& u = f->dev->unchecked;
+            u.erase(std::remove(u.begin(), u.end(), c), u.end());
         }
     }
     f->cmds.clear();

@@ -312,6 +312,12 @@ def test_pbr_textured_alpha_cutoff_is_reported(mirhi, oracle, device, scenes):
     ref = oracle.render(sc, want_bgra8=False)
     assert np.array_equal(out["prim"], ref["prim"])
     f.destroy()
+    # without a fence the same report comes from wait_idle (once)
+    res.render()
+    with pytest.raises(mirhi.RhiError) as e:
+        device.wait_idle()
+    assert e.value.code == 9 and "alpha cutoff" in e.value.message
+    device.wait_idle()
     res.destroy()
     # the next clean frame clears the condition
     res = mirhi.SceneResources(device, scenes.hello_triangle(64, 64))
