@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build them once -- hipcc cross-compiles libmirhi.so for
+    gfx950 without a GPU (~1 min), gcc / g++ build the oracle, libmiresources.so and the C++ host test."""
+    import glob
+    pkg = os.path.join(ROOT, "renderer-rs_amd")
+    have = (os.path.exists(os.path.join(pkg, "libmirhi.so")) and os.path.exists(os.path.join(pkg, "libmiresources.so"))
+            and glob.glob(os.path.join(ROOT, "oracle", "*.so")))
+    if not have:
+        import __graft_entry__ as ge
+        ge.build()
+
+
 @pytest.fixture(scope="session")
 def mirhi():
     import __graft_entry__ as ge
