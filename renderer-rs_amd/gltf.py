@@ -140,6 +140,17 @@ def _texture_image(doc, info) -> Optional[int]:
 
 
 def load(path: str, images: bool = False) -> Model:
+    """Every failure -- missing file, malformed JSON, an index or accessor that points outside its array or buffer -- is a
+    ResourceError, like `gltf::import(path)?` in the reference (model.rs:113-120)."""
+    try:
+        return _load(path, images)
+    except ResourceError:
+        raise
+    except Exception as e:          # IndexError / KeyError / TypeError / ValueError from a document that lies about itself
+        raise ResourceError(f"Failed to load glTF {path}: {type(e).__name__}: {e}")
+
+
+def _load(path: str, images: bool) -> Model:
     if not os.path.exists(path):
         raise ResourceError(f"File not found: {path}")                      # model.rs:113-115
     try:

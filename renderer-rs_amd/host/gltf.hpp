@@ -130,7 +130,16 @@ struct Model {   // model.rs:46-109
     size_t total_vertices() const { size_t n = 0; for (auto& m : meshes) n += m.vertex_count(); return n; }
     size_t total_triangles() const { size_t n = 0; for (auto& m : meshes) n += m.triangle_count(); return n; }
 
+    // Every failure -- missing file, malformed JSON, an index or an accessor that points outside its array or buffer, an
+    // allocation a hostile count provokes -- leaves as ResourceError, like `gltf::import(path)?` does in the reference.
     static Model load(const std::string& path, ImagePolicy policy = ImagePolicy::Discard) {
+        try { return load_unchecked(path, policy); }
+        catch (const ResourceError&) { throw; }
+        catch (const std::exception& e) { throw ResourceError("Failed to load glTF " + path + ": " + e.what()); }
+    }
+
+private:
+    static Model load_unchecked(const std::string& path, ImagePolicy policy) {
         std::ifstream f(path, std::ios::binary);
         if (!f) throw ResourceError("File not found: " + path);                         // model.rs:113-115
         std::stringstream ss; ss << f.rdbuf();
@@ -264,13 +273,17 @@ private:
         const size_t comps = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT2" ? 4 : type == "MAT3" ? 9 : 16;
         const size_t csize = (ctype == 5120 || ctype == 5121) ? 1 : (ctype == 5122 || ctype == 5123) ? 2 : 4;
         const size_t count = (size_t)acc.at("count").num;
+        if (count > (size_t(1) << 28)) throw ResourceError("glTF: accessor count out of range");
         if (!acc.has("bufferView")) return {nullptr, count, comps * csize, comps, csize, ctype};
         const json::Value& bv = doc.at("bufferViews").at((size_t)acc.at("bufferView").num);
         const std::vector<uint8_t>& raw = buffers.at((size_t)bv.at("buffer").num);
         const size_t start = (size_t)bv.get("byteOffset", 0) + (size_t)acc.get("byteOffset", 0);
         size_t stride = (size_t)bv.get("byteStride", 0);
         if (!stride) stride = comps * csize;
-        if (count && start + stride * (count - 1) + comps * csize > raw.size()) throw ResourceError("glTF: accessor exceeds its buffer");
+        // (overflow-safe: every element takes at least one byte of the buffer, so a count beyond its size is wrong at once)
+        if (count > raw.size() || start > raw.size() || stride > raw.size() ||
+            (count && (count - 1) > (raw.size() - start) / (stride ? stride : 1)) ||
+            (count && start + stride * (count - 1) + comps * csize > raw.size())) throw ResourceError("glTF: accessor exceeds its buffer");
         return {raw.data() + start, count, stride, comps, csize, ctype};
     }
     static std::vector<float> floats(const json::Value& doc, const std::vector<std::vector<uint8_t>>& buffers, size_t index, size_t want) {

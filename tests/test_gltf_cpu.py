@@ -55,6 +55,39 @@ def test_loader_defaults_and_errors(mirhi, tmp_path):
         gltf.load(str(p))
 
 
+def test_documents_that_lie_about_themselves_are_resource_errors(mirhi, tmp_path):
+    """An accessor beyond its buffer, a bufferView index that does not exist, a count of 2^40, broken JSON: ResourceError from
+    the Python loader, and the C++ one (host/gltf.hpp, same cases through tools/fuzz_gltf.cpp under ASan) -- never an
+    IndexError, never a read outside the buffer."""
+    from renderer_rs_amd import gltf
+    import base64
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    uri = "data:application/octet-stream;base64," + base64.b64encode(pos.tobytes()).decode()
+    def doc():
+        return {"asset": {"version": "2.0"}, "buffers": [{"byteLength": 36, "uri": uri}],
+                "bufferViews": [{"buffer": 0, "byteLength": 36}],
+                "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+                "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}]}
+    p = tmp_path / "bad.gltf"
+    cases = []
+    d = doc(); d["accessors"][0]["count"] = 4; cases.append(d)                      # one element past the buffer
+    d = doc(); d["accessors"][0]["count"] = 1 << 40; cases.append(d)
+    d = doc(); d["accessors"][0]["bufferView"] = 7; cases.append(d)
+    d = doc(); d["bufferViews"][0]["buffer"] = 3; cases.append(d)
+    d = doc(); d["bufferViews"][0]["byteOffset"] = 30; cases.append(d)
+    d = doc(); d["meshes"][0]["primitives"][0]["attributes"]["POSITION"] = 5; cases.append(d)
+    d = doc(); d["accessors"][0]["type"] = "VEC9"; cases.append(d)
+    for d in cases:
+        p.write_text(json.dumps(d))
+        with pytest.raises(gltf.ResourceError):
+            gltf.load(str(p))
+    p.write_text(json.dumps(doc())[:-7])
+    with pytest.raises(gltf.ResourceError):
+        gltf.load(str(p))
+    p.write_text(json.dumps(doc()))
+    assert gltf.load(str(p)).meshes[0].vertex_count == 3
+
+
 def test_dancer_scene_renders_with_oracle(oracle, scenes):
     s = scenes.gltf_model(DANCER, 320, 180)
     assert s.num_triangles == 17210
