@@ -202,6 +202,24 @@ def test_mesh_heap_overflows_the_per_xcd_bins(mirhi, oracle, device, scenes):
     _check(out, ref, scene.name, depth=True)
 
 
+def test_maximum_target_size_8192(mirhi, oracle, device, scenes):
+    """The largest frame the viewport range admits (+-8192 px, include/mirhi.h): 8192x8192 = 65,536 tiles, a 256 MB BGRA8
+    target.  Triangles far beyond the guard band, off-screen ones, small ones in the far corner; winning primitive ids
+    bit for bit, sRGB8 within 1 LSB."""
+    scene = scenes.huge_triangle_case(8192, 8192)
+    extra = scenes._tri_verts([(0.97, 0.97, 0.3), (0.9999, 0.97, 0.3), (0.97, 0.9999, 0.3),
+                               (-1.0, 0.99, 0.2), (-0.99, 1.0, 0.2), (-1.0, 1.0, 0.2)])
+    scene.draws.append(scenes.DrawSpec(vertices=extra, stride=24, count=6, cull_mode=scenes.CULL_NONE))
+    res = mirhi.SceneResources(device, scene, mirhi.Format.B8G8R8A8_SRGB, want_prim=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=True)
+    assert np.array_equal(out["prim"], ref["prim"])
+    assert int(np.abs(out["color"].astype(np.int16) - ref["bgra8"].astype(np.int16)).max()) <= 1
+    assert (ref["prim"][-300:, -300:] != 0xFFFFFFFF).any() and (ref["prim"][-100:, :100] != 0xFFFFFFFF).any()
+
+
 def test_submission_order_does_not_change_depth(mirhi, device, scenes):
     """Size-independent property at BASELINE configs[1] size: with LESS and distinct depths the stored depth image is a
     function of the triangle SET; reversing the submission order must leave it bit-identical (and permute prim ids)."""
