@@ -202,6 +202,24 @@ def test_mesh_heap_overflows_the_per_xcd_bins(mirhi, oracle, device, scenes):
     _check(out, ref, scene.name, depth=True)
 
 
+def test_many_draws_equal_one_draw(mirhi, oracle, device, scenes):
+    """The same 12,000 smooth-shaded triangles as one draw and as 1,000 draws of 12 (the per-primitive draw table, the
+    waterfall over the draws present in a wave, draws padded to whole waves in the geometry kernel): identical frames, and
+    the oracle's frame."""
+    base = scenes.random_triangles(12000, 1280, 720, seed=11, rmin=2, rmax=20)
+    v = base.draws[0].vertices.reshape(-1, 6).copy()
+    v[:, 3:6] = np.random.default_rng(3).uniform(0, 1, v[:, 3:6].shape)          # not flat: the fragment program runs
+    one = scenes.Scene("one-draw", 1280, 720, [scenes.DrawSpec(vertices=v, stride=24, count=v.shape[0], cull_mode=scenes.CULL_NONE)])
+    many = scenes.Scene("many-draws", 1280, 720, [scenes.DrawSpec(vertices=v[i * 36:(i + 1) * 36].copy(), stride=24, count=36,
+                                                                  cull_mode=scenes.CULL_NONE) for i in range(1000)])
+    out1, ref = _render_both(mirhi, oracle, device, one, want_depth=True)
+    outn, refn = _render_both(mirhi, oracle, device, many, want_depth=True)
+    _check(out1, ref, one.name, depth=True)
+    _check(outn, refn, many.name, depth=True)
+    assert np.array_equal(out1["prim"], outn["prim"]) and np.array_equal(out1["depth"].view(np.uint32), outn["depth"].view(np.uint32))
+    assert np.array_equal(out1["color"].view(np.uint32), outn["color"].view(np.uint32))
+
+
 def test_maximum_target_size_8192(mirhi, oracle, device, scenes):
     """The largest frame the viewport range admits (+-8192 px, include/mirhi.h): 8192x8192 = 65,536 tiles, a 256 MB BGRA8
     target.  Triangles far beyond the guard band, off-screen ones, small ones in the far corner; winning primitive ids
