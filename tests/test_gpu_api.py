@@ -524,3 +524,31 @@ def test_not_equal_with_depth_write_is_resolved_in_order(mirhi, oracle, device, 
     res.destroy()
     assert np.array_equal(out["prim"], ref["prim"]) and np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32))
     assert np.abs(out["color"] - ref["rgba"]).max() < 1e-4
+
+
+def test_kernel_times_and_event_overhead(mirhi, device, scenes):
+    """SURVEY 8d measurement API: per-kernel device time from HIP event pairs on the submit stream, corrected by the mean of
+    one empty pair sampled behind every profiled frame (mirhi_device_kernel_time / mirhi_device_event_overhead)."""
+    res = mirhi.SceneResources(device, scenes.random_triangles(2000, 640, 360, seed=9), mirhi.Format.B8G8R8A8_SRGB)
+    for _ in range(5):
+        res.render()
+    device.wait_idle()
+    device.set_profiling(True)
+    device.reset_kernel_times()
+    n = 40
+    for _ in range(n):
+        res.render()
+    device.wait_idle()
+    g_ms, g_n = device.kernel_time(mirhi.Kernel.GEOMETRY)
+    r_ms, r_n = device.kernel_time(mirhi.Kernel.RASTER)
+    ov_ms, ov_n = device.event_overhead()
+    device.set_profiling(False)
+    assert g_n == n and r_n == n and ov_n == n
+    assert 0.0005 < ov_ms < 0.05                      # an empty event pair costs microseconds, not milliseconds
+    assert 0.0 < g_ms / n < 1.0 and 0.0 < r_ms / n < 1.0
+    device.reset_kernel_times()
+    assert device.kernel_time(mirhi.Kernel.RASTER) == (0.0, 0) and device.event_overhead()[1] == 0
+    res.render()
+    device.wait_idle()
+    assert device.kernel_time(mirhi.Kernel.RASTER)[1] == 0      # profiling is off: nothing recorded
+    res.destroy()
