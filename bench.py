@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X compute rasterizer (contract in the task statement).
 
-A "step" is one frame: one pass of the hot path (vertex transform -> setup/binning -> tile raster
--> shading -> final colour store) over one synthetic scene whose inputs are already resident in HBM.
-Default workload = BASELINE.json configs[1]: 10k random flat-shaded triangles at 1920x1080,
-B8G8R8A8_SRGB target (the reference's swapchain format).  Metric: Mtris/s (input triangles / s).
+A "step" is one BATCH of `config.frames_per_step` frames; a frame is one pass of the hot path (vertex transform ->
+setup / binning -> tile raster -> shading -> final colour store) over one synthetic scene whose inputs are already
+resident in HBM.  value = triangles x frames_per_step x steps / time.  Batching makes the timed region tens of
+milliseconds whatever --steps says (the driver runs --steps 20 --warmup 5), so the figure is the steady state with
+`frames_in_flight` command buffers in flight and not the ramp-up of a few frames.
 
-N > 1 (torchrun, one rank per GPU):
-  default        every rank renders whole frames (alternate-frame rendering, no data-path
-                 collective): weak scaling, value = N * K * tris / max-over-ranks time
-  --split rows   one frame is split by screen-tile rows across the ranks and the bands are
-                 all-gathered over RCCL/xGMI every frame: strong scaling of a single frame
+N = 1   BASELINE.json configs[1]: 10k random flat-shaded triangles at 1920x1080, B8G8R8A8_SRGB target (the reference's
+        swapchain format).  Metric: Mtris/s (input triangles / s); shaded Mpix/s and overdraw beside it.
+N > 1   one rank per GPU.  `--gpus N` starts the N ranks itself (torch.distributed.run as a CHILD process, before
+        anything touches the GPU) unless a launcher already did (WORLD_SIZE set).  Primary measurement: BASELINE
+        configs[3] -- ONE 1M-triangle 3840x2160 frame split by screen-tile rows across the ranks, the finished BGRA8
+        bands exchanged over RCCL / xGMI through the C ABI (mirhi_comm_all_gather_bands): strong scaling of a frame.
+        `--split none` measures alternate-frame rendering instead (whole frames per rank, no collective, weak scaling).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,118 +32,145 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 WORKLOADS = {
-    "c2": ("BASELINE configs[1]: 10k random triangles, flat shade, 1920x1080", lambda s: s.random_triangles()),
-    "c3": ("BASELINE configs[2] stand-in: 70,312-tri displaced sphere, Phong + 1 point light, 1920x1080", lambda s: s.displaced_sphere()),
-    "c4": ("BASELINE configs[3]: 1M-triangle grid, 3840x2160", lambda s: s.heightfield_grid()),
-    "c5": ("BASELINE configs[4] stand-in: 262,144-tri box hall, 4 lights + textures, 3840x2160", lambda s: s.box_hall()),
+    # name: (description, scene factory, default frames per step)
+    "c2": ("BASELINE configs[1]: 10k random triangles, flat shade, 1920x1080", lambda s: s.random_triangles(), 512),
+    "c3": ("BASELINE configs[2] stand-in: 70,312-tri displaced sphere, Phong + 1 point light, 1920x1080", lambda s: s.displaced_sphere(), 256),
+    "c4": ("BASELINE configs[3]: 1M-triangle grid, 3840x2160", lambda s: s.heightfield_grid(), 32),
+    "c5": ("BASELINE configs[4] stand-in: 262,144-tri box hall, 4 lights + textures, 3840x2160", lambda s: s.box_hall(), 32),
 }
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--split", default="none", choices=["none", "rows"])
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs; > 1 without a launcher: bench.py starts them itself")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 on one GPU, c4 on several")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames in one step (0 = the workload's default)")
+    ap.add_argument("--split", default=None, choices=["none", "rows"], help="N > 1: rows (default) = tile-row split of one frame + "
+                    "RCCL band exchange; none = alternate-frame rendering")
+    ap.add_argument("--gather", default="abi", choices=["abi", "torch"], help="band exchange: mirhi_comm_* (RCCL through the C ABI) or "
+                    "torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--gather-algo", default="direct", choices=["direct", "broadcast"])
     ap.add_argument("--format", default="bgra8", choices=["bgra8", "rgba32f"])
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames (own command buffer + target) overlapped on the GPU; the reference keeps 2 "
                          "(MAX_FRAMES_IN_FLIGHT) + 1 swapchain image")
     ap.add_argument("--profile-pass-only", action="store_true",
-                    help="only the isolated per-kernel timing pass (one frame at a time): the command profiled with rocprofv3")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only for single-box rehearsals")
-    ap.add_argument("--no-split-extra", action="store_true", help="N>1: skip the secondary tile-row-split measurement")
+                    help="skip the timed region: only the per-dispatch timing passes (the command profiled with rocprofv3 --pmc)")
+    ap.add_argument("--timeline-out", default=None, help="write the per-dispatch timeline of the in-flight pass to this JSON file")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only for rehearsals of N > 1 on a one-GPU box")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the secondary measurements (one-GPU reference, AFR)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     return ap.parse_args()
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: N fresh rank processes under torch.distributed.run, started as a child BEFORE this process
+    has made any HIP call (never an exec of a process that has touched the GPU).  Returns the child's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(scene, seconds: float):
-    """The oracle (a C port of the same pipeline; the reference has no CPU path and cannot be built
-    here) timed on this host's cores on whole frames of the same workload for ~`seconds`."""
+    """The oracle (a C port of the same pipeline; the reference has no CPU path and cannot be built here) timed on this host's
+    cores on whole frames of the same workload: all cores (row-band threads) for half of `seconds`, one thread for the rest."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
+
+    def run(threads, budget):
+        ob.render(scene, nthreads=threads, want_bgra8=True)       # warm-up, page-in
+        t0 = time.perf_counter()
+        frames = 0
+        while True:
+            ob.render(scene, nthreads=threads, want_bgra8=True)
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or frames >= 2000:
+                break
+        return round(scene.num_triangles * frames / dt / 1e6, 4), frames, dt
+
     cores = max(1, min(os.cpu_count() or 1, 64))
-    ob.render(scene, nthreads=cores, want_bgra8=True)       # warm-up, page-in
-    t0 = time.perf_counter()
-    frames = 0
-    while True:
-        ob.render(scene, nthreads=cores, want_bgra8=True)
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or frames >= 2000:
-            break
-    return {"value": round(scene.num_triangles * frames / dt / 1e6, 4), "unit": "Mtris/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} whole frames of the same workload in {dt:.1f} s (oracle/mirhi_oracle.c, {cores} row-band threads)"}
+    v_all, f_all, t_all = run(cores, seconds / 2)
+    v_one, f_one, t_one = run(1, seconds / 2)
+    return {"value": v_all, "unit": "Mtris/s", "cores": cores, "kind": "port",
+            "sample": f"{f_all} whole frames of the same workload in {t_all:.1f} s (oracle/mirhi_oracle.c, {cores} row-band threads)",
+            "single_thread": {"value": v_one, "unit": "Mtris/s", "cores": 1, "sample": f"{f_one} whole frames in {t_one:.1f} s"}}
 
 
-def tile_split_measurement(m, multigpu, torch, dist, dev0, rank, world, local_rank, args, barrier):
-    """SURVEY 8e / BASELINE configs[3]: ONE frame (1M triangles, 3840x2160) split by screen-tile rows across the ranks,
-    the bands all-gathered over RCCL/xGMI every frame.  Strong scaling of a single frame; reported beside the primary."""
-    import time as _t
-    scene = m.scenes.heightfield_grid()
-    dev = m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    dev.set_tile_split(rank, world)
-    keep = []
-
-    def wrap(device, usage, arr):
-        t = torch.from_numpy(arr.copy()).cuda()
-        keep.append(t)
-        return m.Buffer.wrap(device, usage, t.data_ptr(), t.numel())
-
-    frame = torch.zeros((multigpu.padded_rows(scene.height, world), scene.width, 4), dtype=torch.uint8, device="cuda")
-    target = m.Image(dev, scene.width, scene.height, m.Format.B8G8R8A8_SRGB, device_ptr=frame.data_ptr())
-    res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB, color_image=target, wrap_buffers=wrap)
-    steps = max(10, min(200, args.steps))
-
-    def step():
-        res.render()
-        multigpu.all_gather_bands(frame, rank, world, via_host=(args.backend == "gloo"))
-
-    for _ in range(5):
-        step()
-    barrier()
-    t0 = _t.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    dt = _t.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    res.destroy()
-    dev.destroy()
-    return {"workload": "c4: 1M-triangle grid, 3840x2160, tile-row split + in-place all-gather of BGRA8 bands",
-            "value": round(scene.num_triangles * steps / dt / 1e6, 3), "unit": "Mtris/s", "ms_per_frame": round(1e3 * dt / steps, 4),
-            "steps": steps, "scaling": "strong", "n_gpus": world}
-
-
-def measured_traffic(workload: str):
-    """HBM bytes per raster_kernel launch from the latest committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected
-    in separate runs and corrected as MI355X_MICROARCH.md prescribes; see profiles/README.md).  Counters cannot be read
-    from inside this process, so the figure is the one measured for the same kernel build and workload, or null."""
+def measured_traffic(workload: str, source_hash: str):
+    """HBM bytes per FRAME (every kernel of the frame: vertex + geometry + raster) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes; profiles/README.md).  Counters
+    cannot be read from inside this process, so the figure is quoted only if it was taken on THIS kernel build (source hash)."""
     import glob
-    best = None
+    best, note = None, "no counters committed for this workload"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + workload + "_hbm_traffic.json"))):
         try:
-            best = json.load(open(path))["raster_kernel"]["hbm_bytes_per_launch"]
+            j = json.load(open(path))
         except Exception:
-            pass
-    return best
+            continue
+        if j.get("kernel_source_sha16") == source_hash and "frame_hbm_bytes" in j:
+            best, note = j, os.path.basename(path)
+        elif best is None:
+            note = f"{os.path.basename(path)} was measured on build {j.get('kernel_source_sha16', '?')}, this is {source_hash}: not quoted"
+    return best, note
+
+
+def summarize_timeline(tl, kernel_names):
+    """tl: [(kernel, lane, begin_us, end_us)] in submission order.  Overlap between consecutive raster kernels (by begin time),
+    the gap between a frame's geometry and raster kernel, and the steady-state frame period."""
+    if not tl:
+        return None
+    by_kernel = {}
+    for k, lane, b, e in tl:
+        by_kernel.setdefault(k, []).append((b, e, lane))
+    out = {"dispatches": len(tl)}
+    for k, v in by_kernel.items():
+        out[kernel_names[k] + "_us"] = round(sum(e - b for b, e, _ in v) / len(v), 3)
+    ras = sorted(by_kernel.get(1, []))
+    if len(ras) > 2:
+        ov = [max(0.0, min(ras[i][1], ras[i + 1][1]) - ras[i + 1][0]) for i in range(len(ras) - 1)]
+        out["raster_overlap_us"] = round(sum(ov) / len(ov), 3)                        # mean overlap with the next raster kernel
+        out["raster_begin_to_begin_us"] = round((ras[-1][0] - ras[0][0]) / (len(ras) - 1), 3)
+        out["frame_period_us"] = round((ras[-1][1] - ras[0][1]) / (len(ras) - 1), 3)  # raster end to raster end
+    gaps, last_geo = [], {}
+    for k, lane, b, e in tl:                                                            # submission order: geometry, then its raster
+        if k == 0:
+            last_geo[lane] = e
+        elif k == 1 and lane in last_geo:
+            gaps.append(b - last_geo.pop(lane))
+    if gaps:
+        out["geometry_to_raster_gap_us"] = round(sum(gaps) / len(gaps), 3)
+    return out
 
 
 def main():
     args = parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a line "
+                         f"whose n_gpus would not be what was asked for")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     m = ge.load_package()
+    from renderer_rs_amd import build as mbuild
     from renderer_rs_amd import multigpu
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: there is no CPU fallback for the measured path")
     if "MIRHI_BENCH_FORCE_DEVICE" in os.environ:          # rehearsal of N > 1 on a one-GPU box (gloo)
@@ -156,51 +189,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    desc, make = WORKLOADS[args.workload]
+    def max_over_ranks(dt: float) -> float:
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    split = world > 1 and (args.split or "rows") == "rows"
+    wname = args.workload or ("c4" if split else "c2")
+    desc, make, default_fps = WORKLOADS[wname]
+    fps = args.frames_per_step if args.frames_per_step > 0 else default_fps
     scene = make(m.scenes)
-    split = args.split == "rows" and world > 1
     fmt = m.Format.B8G8R8A8_SRGB if args.format == "bgra8" else m.Format.R32G32B32A32_SFLOAT
     bpp = 4 if args.format == "bgra8" else 16
+    tris = scene.num_triangles
+    use_abi_gather = split and args.gather == "abi" and args.backend == "nccl"
 
-    stream = torch.cuda.current_stream().cuda_stream
-    dev = m.Device(local_rank, stream=stream)
-    nfif = 1 if split else max(1, min(8, args.frames_in_flight))
-    dev.set_queue_lanes(nfif)
+    keep = []                                 # torch tensors behind the wrapped buffers / targets
+
+    def make_wrap():
+        shared = {}
+
+        def wrap_shared(device, usage, arr):  # geometry / uniforms are uploaded once and shared by all frames in flight
+            key = (usage, arr.size, hashlib.sha1(arr.tobytes()).digest())
+            if key not in shared:
+                t = torch.from_numpy(arr.copy()).cuda()
+                keep.append(t)
+                shared[key] = m.Buffer.wrap(device, usage, t.data_ptr(), t.numel())
+            return shared[key]
+        return wrap_shared
+
+    class Rig:
+        """A device with `lanes` frames in flight: one colour target + command buffer per frame (swapchain images)."""
+
+        def __init__(self, lanes, band=None, rows=None):
+            self.dev = m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+            self.dev.set_queue_lanes(lanes)
+            if band is not None:
+                self.dev.set_tile_split(*band)
+            wrap = make_wrap()
+            self.frames, self.slots, self.counter = [], [], 0
+            for _ in range(lanes):
+                frame = torch.zeros((rows or scene.height, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
+                target = m.Image(self.dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
+                self.frames.append(frame)
+                self.slots.append(m.SceneResources(self.dev, scene, fmt, color_image=target, wrap_buffers=wrap))
+
+        def next_slot(self):
+            i = self.counter % len(self.slots)
+            self.counter += 1
+            return i
+
+        def destroy(self, comm=None):
+            self.dev.wait_idle()
+            if comm is not None:
+                comm.destroy()
+            seen = set()
+            for sl in self.slots:                     # shared buffers are destroyed once
+                sl.objs = [o for o in sl.objs if not (id(o) in seen or seen.add(id(o)))]
+                sl.destroy()
+            self.dev.destroy()
+
+    nfif = max(1, min(8, args.frames_in_flight))
     if split:
-        dev.set_tile_split(rank, world)
+        nfif = min(nfif, 2)
+        rows = multigpu.padded_rows(scene.height, world) if not use_abi_gather else scene.height
+        rig = Rig(nfif, band=(rank, world), rows=rows)
+    else:
+        rig = Rig(nfif)
+    dev = rig.dev
 
-    # inputs and the render target live in HBM as torch tensors; the rasterizer wraps the pointers
-    keep = []
+    comm, rccl_ranks = None, world
+    if use_abi_gather:
+        # the 128-byte RCCL id travels over the launcher's control channel; the data path is the C ABI alone
+        uid = torch.zeros(m.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(m.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        comm = m.Comm(dev, bytes(uid.cpu().numpy().tobytes()), rank, world)
+        rccl_ranks = comm.world()
+    algo = m.GatherAlgo.DIRECT if args.gather_algo == "direct" else m.GatherAlgo.BROADCAST
 
-    def wrap(device, usage, arr):
-        t = torch.from_numpy(arr.copy()).cuda()
-        keep.append(t)
-        return m.Buffer.wrap(device, usage, t.data_ptr(), t.numel())
-
-    rows = multigpu.padded_rows(scene.height, world) if split else scene.height
-    frames, slots = [], []
-    shared = {}
-
-    def wrap_shared(device, usage, arr):     # geometry / uniforms are uploaded once and shared by all frames in flight
-        key = (usage, arr.ctypes.data, arr.size)
-        if key not in shared:
-            shared[key] = wrap(device, usage, arr)
-        return shared[key]
-
-    for _ in range(nfif):                    # one colour target + command buffer per frame in flight (swapchain images)
-        frame = torch.zeros((rows, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
-        target = m.Image(dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
-        frames.append(frame)
-        slots.append(m.SceneResources(dev, scene, fmt, color_image=target, wrap_buffers=wrap_shared))
-    res = slots[0]
-    counter = [0]
+    def frame():
+        i = rig.next_slot()
+        rig.slots[i].render()
+        if split:
+            if comm is not None:
+                comm.all_gather_bands(rig.slots[i].color, rig.slots[i].cmd, algo)
+            else:
+                multigpu.all_gather_bands(rig.frames[i], rank, world, via_host=(args.backend == "gloo"))
 
     def step():
-        i = counter[0] % nfif
-        counter[0] += 1
-        slots[i].render()
-        if split:
-            multigpu.all_gather_bands(frames[i], rank, world, via_host=(args.backend == "gloo"))
+        for _ in range(fps):
+            frame()
 
     for _ in range(args.warmup):
         step()
@@ -209,65 +291,124 @@ def main():
     for _ in range(0 if args.profile_pass_only else args.steps):
         step()
     barrier()
-    dt = max(time.perf_counter() - t0, 1e-9)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(max(time.perf_counter() - t0, 1e-9))
 
-    # per-kernel device time: HIP event pairs recorded on the submit stream around each kernel, K more steps with
-    # ONE frame in flight (frames that overlap on the GPU would stretch each other's kernel durations)
-    dev.set_profiling(True)
+    if split and not args.profile_pass_only:
+        # every rank must now hold the same, complete frame
+        chk = torch.stack([f[:scene.height].to(torch.int64).sum() for f in rig.frames]).cpu() if bpp == 4 else None
+        if chk is not None and world > 1:
+            lo, hi = chk.clone(), chk.clone()
+            if args.backend == "nccl":
+                lo, hi = lo.cuda(), hi.cuda()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo.cpu(), hi.cpu()):
+                raise SystemExit("bench.py: the ranks disagree about the gathered frame (checksums differ): the band exchange is broken")
+
+    # ---- per-dispatch device time (event pair attached to each dispatch: begin -> end on the GPU clock) -------------------
+    prof_frames = max(64, min(1024, fps))
+    # (a) one frame in flight: isolated kernel durations (kernels of different frames cannot stretch each other)
+    dev.wait_idle()
     dev.reset_kernel_times()
-    for i in range(args.steps):
-        slots[0].render()
-    torch.cuda.synchronize()
-    geo_ms, geo_n = dev.kernel_time(m.Kernel.GEOMETRY)
-    ras_ms, ras_n = dev.kernel_time(m.Kernel.RASTER)
-    ov_ms, ov_n = dev.event_overhead()       # already subtracted per launch from the two figures above
-    dev.set_profiling(False)
-
-    split_extra = None
-    if world > 1 and not split and not args.no_split_extra and not args.profile_pass_only:
-        try:
-            split_extra = tile_split_measurement(m, multigpu, torch, dist, dev, rank, world, local_rank, args, barrier)
-        except Exception as e:          # never let the secondary measurement take the primary line down
-            split_extra = {"error": repr(e)}
-
-    frames_total = args.steps * (1 if split else world)
-    tris = scene.num_triangles
-    value = tris * frames_total / dt / 1e6
+    dev.set_profiling(m.Profile.TIMING)
+    for _ in range(prof_frames):
+        rig.slots[0].render()
+    dev.wait_idle()
+    iso = {name: dev.kernel_time(k) for k, name in enumerate(m.Kernel.NAMES)}
+    iso_tl = summarize_timeline(dev.timeline(), m.Kernel.NAMES)
+    # (b) the timed region's conditions: all lanes in flight (no band exchange: kernels only)
+    dev.reset_kernel_times()
+    for _ in range(prof_frames):
+        rig.slots[rig.next_slot()].render()
+    dev.wait_idle()
+    flight_tl_raw = dev.timeline()
+    flight_tl = summarize_timeline(flight_tl_raw, m.Kernel.NAMES)
+    dev.set_profiling(0)
+    if args.timeline_out and rank == 0:
+        with open(args.timeline_out, "w") as f:
+            json.dump({"kernels": m.Kernel.NAMES, "frames_in_flight": nfif, "dispatches": flight_tl_raw}, f)
+    # (c) fragment statistics: never part of a timed frame
+    dev.reset_kernel_times()
+    dev.set_profiling(m.Profile.FRAGMENTS)
+    for _ in range(2):
+        rig.slots[0].render()
+    dev.set_profiling(0)
+    shaded, covered, scopes = dev.fragment_stats()
+    stat_frames = 2
+    dev.reset_kernel_times()
     stats = dev.stats()
 
+    extras = {}
+    if world > 1 and not args.no_extras and not args.profile_pass_only:
+        try:
+            # the same workload, whole frame on ONE GPU (every rank renders its own copy: no exchange): the N = 1 point of the curve
+            ref = Rig(min(4, max(1, args.frames_in_flight))) if split else None
+            if ref is not None:
+                n = max(8, fps)
+                for _ in range(n // 4):
+                    ref.slots[ref.next_slot()].render()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    ref.slots[ref.next_slot()].render()
+                barrier()
+                d1 = max_over_ranks(time.perf_counter() - t1)
+                extras["one_gpu_same_workload"] = {"value": round(tris * n / d1 / 1e6, 3), "unit": "Mtris/s", "frames": n,
+                                                   "note": "whole frame per GPU, no split, no exchange (all ranks at once, slowest rank)"}
+                ref.destroy()
+        except Exception as e:          # never let a secondary measurement take the primary line down
+            extras["one_gpu_same_workload"] = {"error": repr(e)}
+
     if rank == 0:
+        frames_total = args.steps * fps * (1 if split or world == 1 else world)
+        value = tris * frames_total / dt / 1e6
         alg_bytes = scene.algorithmic_bytes(bpp_out=bpp)
         if split:   # all geometry + this rank's share of the frame buffer
             alg_bytes = alg_bytes - scene.width * scene.height * bpp + scene.width * scene.height * bpp // world
+        ras_ms, ras_n = iso["raster"]
+        geo_ms, geo_n = iso["geometry"]
+        vs_ms, vs_n = iso["vertex"]
         ras_us = 1e3 * ras_ms / max(1, ras_n)
         geo_us = 1e3 * geo_ms / max(1, geo_n)
+        vs_us = 1e3 * vs_ms / max(1, vs_n)
         achieved = alg_bytes / (ras_us * 1e-6) / 1e9 if ras_us > 0 else 0.0
+        frame_us = ras_us + geo_us + vs_us
+        src_hash = mbuild.source_hash()
+        traffic, traffic_note = (None, "split run") if split else measured_traffic(wname, src_hash)
+        shaded_per_frame = shaded / max(1, stat_frames)
         out = {
             "metric": "Mtris/s at 1920x1080 (input triangles per second, whole frame incl. shading + store)"
                       if scene.height == 1080 else "Mtris/s (input triangles per second, whole frame incl. shading + store)",
-            "value": round(value, 3), "unit": "Mtris/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 6), "higher_is_better": True,
+            "value": round(value, 3), "unit": "Mtris/s", "n_gpus": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / max(1, args.steps), 6), "higher_is_better": True,
             "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "f32+i32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "triangles": tris, "width": scene.width, "height": scene.height,
+            "config": {"workload": f"{wname}: {desc}", "triangles": tris, "width": scene.width, "height": scene.height,
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
-                       "parallelism": (f"tile-row split x{world} + RCCL all-gather" if split else (f"afr{world}" if world > 1 else "single")),
-                       "frames_per_step": 1, "frames_in_flight": nfif},
-            "shaded_mpix_per_s": round(scene.width * scene.height * frames_total / dt / 1e6, 1),
+                       "parallelism": (f"tile-row split x{world} + RCCL band exchange ({args.gather}/{args.gather_algo})" if split
+                                       else (f"afr{world}" if world > 1 else "single")),
+                       "frames_per_step": fps, "frames_in_flight": nfif},
+            "timed_region_s": round(dt, 6), "us_per_frame": round(1e6 * dt / max(1, args.steps * fps), 4),
+            "shaded_mpix_per_s": round(shaded_per_frame * frames_total / dt / 1e6, 1),
+            "overdraw": round(covered / shaded, 4) if shaded else None,
+            "shaded_pixels_per_frame": int(shaded_per_frame), "covered_fragments_per_frame": int(covered / max(1, stat_frames)),
+            "target_mpix_per_s": round(scene.width * scene.height * frames_total / dt / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None if split else measured_traffic(args.workload),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic["frame_hbm_bytes"] if traffic else None, "traffic_scope": "whole frame: vertex + geometry + raster kernels",
+                         "traffic_source": traffic_note, "kernel_source_sha16": src_hash,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": round(ras_us, 3),
-                         "geometry_kernel_us": round(geo_us, 3),
-                         "event_pair_overhead_us": round(1e3 * ov_ms, 3), "event_pair_samples": ov_n,
-                         "how": "hipEvent pairs on the submit stream around every launch, minus the mean of one EMPTY pair recorded behind each frame's raster pair; K extra steps after the timed region, one frame in flight so kernels of different frames do not overlap"},
+                         "geometry_kernel_us": round(geo_us, 3), "vertex_kernel_us": round(vs_us, 3),
+                         "frame_kernels_us": round(frame_us, 3),
+                         "frame_frac": round(alg_bytes / (frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if frame_us > 0 else None,
+                         "timed_launches": ras_n,
+                         "how": "event pair attached to every dispatch (hipExtLaunchKernelGGL start/stop events = the dispatch's begin and end on "
+                                "the GPU clock, as rocprofv3 --kernel-trace reports them; nothing subtracted); a pass of frames behind the timed "
+                                "region with ONE frame in flight, so kernels of different frames do not stretch each other"},
+            "timeline_isolated": iso_tl, "timeline_in_flight": flight_tl,
             "workspace_mb": round(stats.workspace_bytes / 1e6, 1), "big_list": stats.last_big_list,
         }
-        if split_extra is not None:
-            out["tile_split"] = split_extra
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1 and not args.profile_pass_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_seconds)
@@ -275,11 +416,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
-    seen = set()
-    for sl in slots:                          # shared buffers are destroyed once
-        sl.objs = [o for o in sl.objs if not (id(o) in seen or seen.add(id(o)))]
-        sl.destroy()
-    dev.destroy()
+    rig.destroy(comm)
     if world > 1:
         dist.destroy_process_group()
 

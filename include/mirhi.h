@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MIRHI_ABI_VERSION 1u
+#define MIRHI_ABI_VERSION 2u
 
 /* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
 typedef int32_t mirhi_result;
@@ -242,17 +242,30 @@ mirhi_result mirhi_fence_reset(mirhi_fence* fence);                             
 mirhi_result mirhi_fence_status(mirhi_fence* fence);    /* MIRHI_OK = signaled, MIRHI_NOT_READY = unsignaled; Fence::is_signaled :294 */
 mirhi_result mirhi_fence_destroy(mirhi_fence* fence);
 
-/* ---- measurement: per-kernel device time from HIP events on the submit stream ---------- */
-typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_COUNT = 2 } mirhi_kernel_id;
-mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);   /* brackets each kernel with hipEvents */
-/* accumulated since the last reset; waits for outstanding events.  An event pair costs stream time even around nothing
- * (~4.6 us on MI355X); every profiled scope therefore also records one EMPTY pair behind its raster pair, and the mean of
- * those in-situ samples is subtracted per launch (before any scope has run: a one-off calibration taken when profiling
- * is enabled), so the figure is the kernel's own duration as rocprofv3 --kernel-trace sees it. */
+/* ---- measurement: per-dispatch device time, fragment statistics ---------------------------------- */
+typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_VERTEX = 2, MIRHI_KERNEL_FRAGMENT_COUNT = 3,
+               MIRHI_KERNEL_COUNT = 4 } mirhi_kernel_id;
+/* enable: 0 = off, or a mask of
+ *   MIRHI_PROFILE_TIMING     every kernel dispatch carries its own event pair (hipExtLaunchKernelGGL start / stop events): the
+ *                            duration is the dispatch's begin -> end on the GPU clock, as rocprofv3 --kernel-trace reports it;
+ *                            no event-record commands enter the stream and nothing is subtracted
+ *   MIRHI_PROFILE_FRAGMENTS  fragment statistics (below): one extra counting kernel per scope and a few instructions in the
+ *                            resolve -- never combine with a throughput measurement */
+enum { MIRHI_PROFILE_TIMING = 1, MIRHI_PROFILE_FRAGMENTS = 2 };
+mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);
+/* accumulated since the last reset; waits for outstanding dispatches */
 mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches);
-/* the per-launch correction mirhi_device_kernel_time applies, and the number of in-situ samples behind it (0 = calibration) */
-mirhi_result mirhi_device_event_overhead(mirhi_device* dev, double* overhead_ms, uint64_t* samples);
-mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev);
+/* every timed dispatch since the last reset, in submission order: begin / end in microseconds on one GPU time axis that starts
+ * at the begin of the first of them -- overlap between the queue lanes' kernels and the gaps between dependent launches can be
+ * read off directly.  Writes min(capacity, *count) records; `out` may be NULL to query the count. */
+typedef struct { uint32_t kernel /* mirhi_kernel_id */, lane; double begin_us, end_us; } mirhi_dispatch_time;
+mirhi_result mirhi_device_timeline(mirhi_device* dev, mirhi_dispatch_time* out, uint32_t capacity, uint32_t* count);
+/* SURVEY 8d "shaded Mpix/s ... report overdraw separately", summed over the scopes rendered with MIRHI_PROFILE_FRAGMENTS since
+ * the last reset: shaded_pixels = pixels whose fragment program ran (the winners of the depth resolve: this design shades
+ * visible pixels only), covered_fragments = pixel centres covered by a triangle before any depth test (what a GPU's
+ * rasterizer emits); overdraw = covered_fragments / shaded_pixels.  Blended (ordered) segments are not counted. */
+mirhi_result mirhi_device_fragment_stats(mirhi_device* dev, uint64_t* shaded_pixels, uint64_t* covered_fragments, uint64_t* scopes);
+mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev);   /* also clears the timeline and the fragment statistics */
 typedef struct {
     uint64_t frames_submitted;      /* rendering scopes executed */
     uint64_t triangles_submitted;   /* input triangles over those scopes */
@@ -261,6 +274,34 @@ typedef struct {
     uint32_t last_status;           /* device status word of the last finished scope (0 = ok) */
 } mirhi_device_stats;
 mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out);
+
+/* ---- multi-GPU: screen-tile-row split + exchange of the finished RGBA bands over RCCL / xGMI ------------------
+ * The reference drives one VkDevice (crates/rhi/src/device.rs:61-77) and has nothing to mirror here; BASELINE.json's north_star
+ * defines the split.  One process per GPU: every rank creates its device, calls mirhi_device_set_tile_split(rank, world)
+ * (mirhi_comm_create does it), renders -- only its band of 32-pixel tile rows is rasterized -- and calls
+ * mirhi_comm_all_gather_bands on the frame: afterwards every rank holds the whole image.  librccl is loaded with dlopen the
+ * first time one of these functions runs: a single-GPU host never loads or initialises RCCL. */
+typedef struct mirhi_comm mirhi_comm;
+#define MIRHI_COMM_ID_BYTES 128                     /* = NCCL_UNIQUE_ID_BYTES */
+/* rank 0: fills `id` (ncclGetUniqueId); ship the 128 bytes to the other ranks over any host channel (the launcher's) */
+mirhi_result mirhi_comm_unique_id(uint8_t* id /* [MIRHI_COMM_ID_BYTES] */);
+/* collective over all `world` ranks (ncclCommInitRank); also applies mirhi_device_set_tile_split(dev, rank, world) */
+mirhi_result mirhi_comm_create(mirhi_device* dev, const uint8_t* id, uint32_t rank, uint32_t world, mirhi_comm** out);
+uint32_t mirhi_comm_world(const mirhi_comm* comm);  /* ranks RCCL counts in the communicator (ncclCommCount) */
+uint32_t mirhi_comm_rank(const mirhi_comm* comm);
+typedef enum {
+    MIRHI_GATHER_DIRECT = 0,      /* one grouped batch of ncclSend / ncclRecv: every rank sends its band straight to every peer --
+                                     xGMI is a full mesh of point-to-point links, so the 7 transfers of a rank run in parallel
+                                     (4K BGRA8 on 8 GPUs: 4.15 MB per link) where a ring would pass 7 hops one after another */
+    MIRHI_GATHER_BROADCAST = 1    /* one grouped batch of `world` in-place ncclBroadcast, one band each; RCCL picks the algorithm */
+} mirhi_gather_algo;
+/* In place on `frame` (a colour image every rank created with the same extent and format): rank r's rows
+ * [band_begin(r), band_end(r)) -- mirhi_device_band_rows -- are sent, the other bands received.  Bands may differ in size (the last
+ * one is short when the tile rows do not divide).  Enqueued on the queue lane of `after` (the command buffer that rendered the
+ * frame; NULL = lane 0), so it runs behind that frame's raster kernel; completion through mirhi_device_wait_idle or a later
+ * submit on the same lane. */
+mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_image* frame, mirhi_cmd* after, mirhi_gather_algo algo);
+mirhi_result mirhi_comm_destroy(mirhi_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,19 @@ class TextureSlot:
 
 
 class Kernel:
-    GEOMETRY, RASTER = range(2)
+    GEOMETRY, RASTER, VERTEX, FRAGMENT_COUNT = range(4)
+    NAMES = ("geometry", "raster", "vertex", "fragment_count")
+
+
+class Profile:
+    TIMING, FRAGMENTS = 1, 2
+
+
+class GatherAlgo:
+    DIRECT, BROADCAST = range(2)
+
+
+COMM_ID_BYTES = 128
 
 
 MAX_FRAMES_IN_FLIGHT = 2  # crates/renderer/src/lib.rs:43
@@ -129,6 +141,10 @@ class Viewport(C.Structure):
 
 class Rect2D(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class DispatchTime(C.Structure):
+    _fields_ = [("kernel", C.c_uint32), ("lane", C.c_uint32), ("begin_us", C.c_double), ("end_us", C.c_double)]
 
 
 class DeviceStats(C.Structure):
@@ -213,7 +229,14 @@ _SIGNATURES = {
     "mirhi_device_set_profiling": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_kernel_time": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "mirhi_device_reset_kernel_times": (C.c_int32, [C.c_void_p]),
-    "mirhi_device_event_overhead": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "mirhi_device_timeline": (C.c_int32, [C.c_void_p, C.POINTER(DispatchTime), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mirhi_device_fragment_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mirhi_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "mirhi_comm_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "mirhi_comm_world": (C.c_uint32, [C.c_void_p]),
+    "mirhi_comm_rank": (C.c_uint32, [C.c_void_p]),
+    "mirhi_comm_all_gather_bands": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mirhi_comm_destroy": (C.c_int32, [C.c_void_p]),
     "mirhi_device_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(DeviceStats)]),
 }
 
@@ -283,7 +306,8 @@ class Device:
         check(lib().mirhi_device_band_rows(self.handle, height, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def set_profiling(self, enable: bool):
+    def set_profiling(self, enable):
+        """False / 0 = off, True = Profile.TIMING, or a mask of Profile.TIMING | Profile.FRAGMENTS."""
         check(lib().mirhi_device_set_profiling(self.handle, int(enable)))
 
     def kernel_time(self, kernel: int):
@@ -291,11 +315,19 @@ class Device:
         check(lib().mirhi_device_kernel_time(self.handle, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def event_overhead(self):
-        """(milliseconds subtracted per launch by kernel_time, in-situ samples behind it)"""
-        ms, n = C.c_double(0), C.c_uint64(0)
-        check(lib().mirhi_device_event_overhead(self.handle, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+    def timeline(self):
+        """Every timed dispatch since the last reset: list of (kernel, lane, begin_us, end_us) on one GPU time axis."""
+        n = C.c_uint32(0)
+        check(lib().mirhi_device_timeline(self.handle, None, 0, C.byref(n)))
+        arr = (DispatchTime * max(1, n.value))()
+        check(lib().mirhi_device_timeline(self.handle, arr, n.value, C.byref(n)))
+        return [(arr[i].kernel, arr[i].lane, arr[i].begin_us, arr[i].end_us) for i in range(n.value)]
+
+    def fragment_stats(self):
+        """(shaded pixels, covered fragments, scopes) accumulated under Profile.FRAGMENTS since the last reset."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().mirhi_device_fragment_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def reset_kernel_times(self):
         check(lib().mirhi_device_reset_kernel_times(self.handle))
@@ -608,6 +640,38 @@ class Fence:
             self.handle = None
 
 
+class Comm:
+    """Exchange of the finished bands of a tile-row split over RCCL (include/mirhi.h; no reference counterpart:
+    crates/rhi/src/device.rs:61-77 drives a single VkDevice)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        check(lib().mirhi_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, device: Device, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == COMM_ID_BYTES
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().mirhi_comm_create(device.handle, buf, rank, world, C.byref(h)))
+        self.handle, self.device = h, device
+
+    def world(self) -> int:
+        return lib().mirhi_comm_world(self.handle)
+
+    def rank(self) -> int:
+        return lib().mirhi_comm_rank(self.handle)
+
+    def all_gather_bands(self, frame: Image, after: Optional["CommandBuffer"] = None, algo: int = GatherAlgo.DIRECT):
+        check(lib().mirhi_comm_all_gather_bands(self.handle, frame.handle, after.handle if after else None, algo))
+
+    def destroy(self):
+        if self.handle:
+            check(lib().mirhi_comm_destroy(self.handle))
+            self.handle = None
+
+
 # ---- scene helper: records a scenes.Scene the way crates/renderer records a frame ---------------------------
 class SceneResources:
     """Uploads a scenes.Scene once (vertex/index/uniform buffers, textures, pipelines) and records it into
@@ -615,8 +679,11 @@ class SceneResources:
     (crates/renderer/src/renderer.rs:205-260,452-557)."""
 
     def __init__(self, device: Device, scene, color_format: int = Format.R32G32B32A32_SFLOAT, want_prim: bool = False,
-                 want_depth: bool = False, color_image: Optional[Image] = None, wrap_buffers=None):
+                 want_depth: bool = False, color_image: Optional[Image] = None, wrap_buffers=None,
+                 color_load_op: int = LoadOp.CLEAR):
         self.device, self.scene = device, scene
+        self.color_load_op = color_load_op
+        self.owns_color = color_image is None
         self.objs = []
         self.color = color_image or Image(device, scene.width, scene.height, color_format)
         self.color_format = self.color.format
@@ -686,7 +753,7 @@ class SceneResources:
     def record(self):
         s, cmd = self.scene, self.cmd
         cmd.begin_reusable()
-        cmd.begin_rendering(self.color, clear_color=s.clear_color, depth=self.depth, clear_depth=s.clear_depth,
+        cmd.begin_rendering(self.color, clear_color=s.clear_color, color_load_op=self.color_load_op, depth=self.depth, clear_depth=s.clear_depth,
                             depth_store_op=StoreOp.STORE if self.depth else StoreOp.DONT_CARE, prim_id=self.prim)
         for st in self.draw_state:
             d = st["draw"]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmirhi.so")
 SOURCES = ["mirhi_kernels.hip", "mirhi_api.hip"]
-HEADERS = ["mirhi_device.h", "mirhi_launch.h", "mirhi_common.hip.h", "mirhi_geometry.hip.h", "mirhi_shading.hip.h", "mirhi_raster.hip.h", "mirhi_ordered.hip.h", os.path.join("..", "..", "include", "mirhi.h")]
+HEADERS = ["mirhi_device.h", "mirhi_launch.h", "mirhi_common.hip.h", "mirhi_geometry.hip.h", "mirhi_shading.hip.h", "mirhi_raster.hip.h", "mirhi_ordered.hip.h", "mirhi_stats.hip.h", os.path.join("..", "..", "include", "mirhi.h")]
 # -ffp-contract=off: coverage/depth arithmetic must match the oracle bit for bit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -29,6 +29,19 @@ def needs_build() -> bool:
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel and C-ABI sources: tags measurements (profiles/*_hbm_traffic.json) with the
+    build they were taken on, so that bench.py never quotes counters of another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        path = os.path.join(CSRC, name)
+        if os.path.exists(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, suffix: str = "") -> str:

@@ -20,6 +20,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types and prototypes only: librccl is loaded with dlopen on first use (no link-time dependency)
+
 #include "../../include/mirhi.h"
 #include "mirhi_device.h"
 #include "mirhi_launch.h"
@@ -78,7 +81,9 @@ extern "C" const char* mirhi_result_name(mirhi_result r) {
 // ------------------------------------------------------------------------------------------------
 // objects
 // ------------------------------------------------------------------------------------------------
-struct EventPair { hipEvent_t a, b; };
+// One timed dispatch: the event pair is attached to the dispatch itself (hipExtLaunchKernelGGL), so elapsed(start, stop) is
+// the kernel's begin -> end on the GPU clock and elapsed(stop of A, stop of B) the distance between two kernels' ends.
+struct TimedDispatch { hipEvent_t start, stop; uint32_t kernel, lane; };
 
 struct mirhi_device {
     int ordinal = 0;
@@ -88,17 +93,22 @@ struct mirhi_device {
     uint32_t next_lane = 0;
     std::atomic<int> children{0};
     uint32_t split_rank = 0, split_world = 1;
-    bool profiling = false;
+    uint32_t profiling = 0;                  // MIRHI_PROFILE_* bits
     std::mutex mu;
-    std::vector<EventPair> pending[MIRHI_KERNEL_COUNT];
+    std::vector<TimedDispatch> pending;       // timed dispatches not yet read back
+    std::vector<mirhi_dispatch_time> timeline;   // read back: begin / end relative to the first one since the last reset
+    hipEvent_t base_stop = nullptr;           // stop event of that first dispatch (kept until the next reset)
+    double base_end_ms = 0.0;                 //   its end on the timeline (= its own duration: the timeline starts at its begin)
+    std::vector<hipEvent_t> free_events;
     std::vector<mirhi_cmd*> unchecked;        // submitted since the last wait_idle: their status words are read there
-    std::vector<EventPair> pending_empty;     // one EMPTY pair per profiled scope, recorded right behind the raster pair
-    std::vector<EventPair> free_events;
-    double event_overhead_ms = 0.0;          // calibrated duration of an EMPTY hipEvent pair on the submit stream
-    double empty_ms = 0.0;                   // in-situ empty pairs since the last reset: same stream, same clocks, same
-    uint64_t empty_n = 0;                    //   queue state as the kernel pairs they correct
-    double total_ms[MIRHI_KERNEL_COUNT] = {0, 0};
-    uint64_t launches[MIRHI_KERNEL_COUNT] = {0, 0};
+    std::vector<mirhi_fence*> fences;         // live fences (guarded by mu): a command buffer that is destroyed or re-recorded
+                                              //   while a fence still lists it hands its device status over first
+    mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
+    std::string deferred_msg;
+    double total_ms[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
+    uint64_t launches[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
+    unsigned long long* frag_stats = nullptr; // device: [0] pixels that ran a fragment program, [1] covered fragments (profiling only)
+    uint64_t frag_scopes = 0;                 // scopes counted into frag_stats since the last reset
     mirhi_device_stats stats{};
     char name[256] = {0};
 };
@@ -156,6 +166,10 @@ struct Workspace {
     uint32_t* status_dev = nullptr;                              // device view of status_host
     uint32_t* big_counts = nullptr;                              // two counters, used alternately (parity)
     uint32_t parity = 0;
+    // statistics pass (MIRHI_PROFILE_FRAGMENTS), built on first use: a primitive-id image of the workspace's own and copies
+    // of the scopes' parameters that write it, so that the product kernels and parameters stay untouched
+    uint32_t* stats_prim = nullptr; size_t stats_prim_bytes = 0;
+    PassParams* stats_params = nullptr; size_t stats_params_bytes = 0; bool stats_params_valid = false;
     size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes + flat_color_bytes; }
 };
 
@@ -191,6 +205,8 @@ struct mirhi_fence {
     bool signaled = false;      // host-visible signaled state
     bool pending = false;       // an event record is outstanding
     std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
+    mirhi_result deferred = MIRHI_OK;   // status handed over by a listed command buffer that was destroyed / re-recorded since
+    std::string deferred_msg;
 };
 
 static uint32_t format_bpp(mirhi_format f) {
@@ -237,6 +253,14 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
         d->owns_stream = true;
     }
     d->lanes.push_back(d->stream);
+    {
+        const hipError_t fe = hipMalloc((void**)&d->frag_stats, 2 * sizeof(unsigned long long));
+        if (fe != hipSuccess || hipMemset(d->frag_stats, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+            if (d->owns_stream) (void)hipStreamDestroy(d->stream);
+            delete d; (void)hipGetLastError();
+            return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc for the device statistics block");
+        }
+    }
     {   // sRGB EOTF per byte, evaluated in double and rounded once (the oracle builds the identical table)
         float lut[256];
         for (int i = 0; i < 256; i++) {
@@ -283,9 +307,10 @@ extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: device still has %d live child objects", dev->children.load());
     (void)sync_all_lanes(dev);
     for (size_t i = 1; i < dev->lanes.size(); i++) (void)hipStreamDestroy(dev->lanes[i]);
-    for (auto& v : dev->pending) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto& p : dev->pending_empty) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    for (auto& p : dev->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : dev->pending) { if (p.start != dev->base_stop) (void)hipEventDestroy(p.start); if (p.stop != dev->base_stop) (void)hipEventDestroy(p.stop); }
+    if (dev->base_stop) (void)hipEventDestroy(dev->base_stop);
+    for (auto& e : dev->free_events) (void)hipEventDestroy(e);
+    if (dev->frag_stats) (void)hipFree(dev->frag_stats);
     if (dev->owns_stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return MIRHI_OK;
@@ -302,9 +327,9 @@ extern "C" mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t 
     dev->split_rank = rank; dev->split_world = world;
     return MIRHI_OK;
 }
-static void band_tile_rows(const mirhi_device* dev, uint32_t tiles_y, uint32_t* r0, uint32_t* r1) {
-    const uint32_t per = (tiles_y + dev->split_world - 1) / dev->split_world;   // contiguous bands, last rank short
-    uint32_t b = dev->split_rank * per, e = b + per;
+static void band_tile_rows(uint32_t rank, uint32_t world, uint32_t tiles_y, uint32_t* r0, uint32_t* r1) {
+    const uint32_t per = (tiles_y + world - 1) / world;   // contiguous bands, last rank short
+    uint32_t b = rank * per, e = b + per;
     if (b > tiles_y) b = tiles_y;
     if (e > tiles_y) e = tiles_y;
     *r0 = b; *r1 = e;
@@ -313,7 +338,7 @@ extern "C" mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t heigh
     NULL_CHECK(dev, "device"); NULL_CHECK(row_begin, "row_begin"); NULL_CHECK(row_end, "row_end");
     const uint32_t tiles_y = (height + TILE - 1) / TILE;
     uint32_t r0, r1;
-    band_tile_rows(dev, tiles_y, &r0, &r1);
+    band_tile_rows(dev->split_rank, dev->split_world, tiles_y, &r0, &r1);
     uint32_t p0 = r0 * TILE, p1 = r1 * TILE;
     if (p0 > height) p0 = height;
     if (p1 > height) p1 = height;
@@ -630,8 +655,39 @@ static void free_workspace(mirhi_cmd* c) {
     if (w.vs_out) (void)hipFree(w.vs_out);
     if (w.flat_color) (void)hipFree(w.flat_color);
     if (w.prim_draw) (void)hipFree(w.prim_draw);
+    if (w.stats_prim) (void)hipFree(w.stats_prim);
+    if (w.stats_params) (void)hipFree(w.stats_params);
     if (w.status_host) (void)hipHostFree(w.status_host);
     w = Workspace();
+}
+
+// The device-side status of a finished submission lives in the command buffer's workspace.  Before that workspace goes away
+// (destroy) or is re-armed (end() of a new recording) every fence that still lists the command buffer -- Vulkan allows
+// destroying a command buffer before its fence is waited on, and the Rust wrapper's Drop order does exactly that -- takes the
+// status over; so does the device's wait_idle bookkeeping.  The caller has synchronised the command buffer's lane.
+static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c);
+static void hand_over_status(mirhi_cmd* cmd) {
+    mirhi_device* dev = cmd->dev;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    auto& u = dev->unchecked;
+    const bool was_unchecked = std::find(u.begin(), u.end(), cmd) != u.end();
+    bool listed = false;
+    for (mirhi_fence* f : dev->fences) listed |= std::find(f->cmds.begin(), f->cmds.end(), cmd) != f->cmds.end();
+    if (!was_unchecked && !listed) return;
+    const std::string keep = g_last_error;
+    const mirhi_result rc = status_of(dev, cmd);
+    const std::string msg = g_last_error;
+    g_last_error = keep;
+    for (mirhi_fence* f : dev->fences) {
+        auto it = std::remove(f->cmds.begin(), f->cmds.end(), cmd);
+        if (it == f->cmds.end()) continue;
+        f->cmds.erase(it, f->cmds.end());
+        if (rc != MIRHI_OK) { f->deferred = rc; f->deferred_msg = msg; }
+    }
+    if (was_unchecked) {
+        u.erase(std::remove(u.begin(), u.end(), cmd), u.end());
+        if (rc != MIRHI_OK && !listed) { dev->deferred = rc; dev->deferred_msg = msg; }
+    }
 }
 
 extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
@@ -647,11 +703,7 @@ extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
 extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
     (void)sync_all_lanes(cmd->dev);
-    {
-        std::lock_guard<std::mutex> lock(cmd->dev->mu);
-        auto& u = cmd->dev->unchecked;
-        u.erase(std::remove(u.begin(), u.end(), cmd), u.end());
-    }
+    hand_over_status(cmd);          // fences (and wait_idle) that still list this command buffer keep its device status
     free_workspace(cmd);
     cmd->dev->children--;
     delete cmd;
@@ -1004,7 +1056,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         const mirhi_image* ci = pass.info.color_image;
         Geo g;
         g.tiles_x = (ci->width + TILE - 1) / TILE; g.tiles_y = (ci->height + TILE - 1) / TILE;
-        band_tile_rows(dev, g.tiles_y, &g.r0, &g.r1);
+        band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
         size_t cap = tiles ? (8ull * pass.total_tris) / tiles + 64 : 64;
         {   // A mesh concentrates its triangles in the tiles it covers (the dancer asset: 17k triangles in 232 of 2040 tiles,
@@ -1046,6 +1098,8 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         HIP_TRY(hipHostMalloc((void**)&w.status_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer((void**)&w.status_dev, w.status_host, 0));
     }
+    w.stats_params_valid = false;
+    hand_over_status(cmd);          // an earlier submission's status is not lost to the re-arm below
     w.status_host[0] = 0; w.status_host[1] = 0;
     w.big_counts = w.counters + 8 * max_tiles;
     w.parity = 0;
@@ -1162,6 +1216,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
+        P.frag_stats = dev->frag_stats;
         P.first_prim = pass.first_tri;
         P.prim_draw = pass.draws.size() > 1 ? w.prim_draw : nullptr;
         {
@@ -1226,10 +1281,38 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
 // ------------------------------------------------------------------------------------------------
 // submit + fences
 // ------------------------------------------------------------------------------------------------
-static mirhi_result profile_begin(mirhi_device* dev, hipStream_t stream, EventPair* ev) {
-    if (!dev->free_events.empty()) { *ev = dev->free_events.back(); dev->free_events.pop_back(); }
-    else { HIP_TRY(hipEventCreate(&ev->a)); HIP_TRY(hipEventCreate(&ev->b)); }
-    HIP_TRY(hipEventRecord(ev->a, stream));
+// Statistics pass: device copies of the command buffer's scope parameters (both parities) whose primitive-id image is the
+// workspace's own, built the first time a recorded command buffer is submitted with MIRHI_PROFILE_FRAGMENTS.
+static mirhi_result stats_params_for(mirhi_cmd* c) {
+    Workspace& w = c->ws;
+    if (w.stats_params_valid) return MIRHI_OK;
+    size_t pixels = 0;
+    for (const PassParams& P : c->plan) pixels = std::max(pixels, (size_t)P.width * P.height);
+    mirhi_result r;
+    if ((r = grow(&w.stats_prim, &w.stats_prim_bytes, (pixels ? pixels : 1) * 4)) != MIRHI_OK) return r;
+    if ((r = grow(&w.stats_params, &w.stats_params_bytes, (c->plan.size() ? c->plan.size() : 1) * 2 * sizeof(PassParams))) != MIRHI_OK) return r;
+    std::vector<PassParams> copies;
+    for (const PassParams& P0 : c->plan)
+        for (uint32_t parity = 0; parity < 2; parity++) {
+            PassParams P = P0;
+            P.big_count = w.big_counts + parity;
+            P.big_count_next = w.big_counts + (parity ^ 1u);
+            P.prim_out = w.stats_prim;
+            copies.push_back(P);
+        }
+    if (!copies.empty()) HIP_TRY(hipMemcpy(w.stats_params, copies.data(), copies.size() * sizeof(PassParams), hipMemcpyHostToDevice));
+    w.stats_params_valid = true;
+    return MIRHI_OK;
+}
+
+static mirhi_result timing_begin(mirhi_device* dev, uint32_t kernel, uint32_t lane, LaunchTiming* t) {
+    hipEvent_t ev[2];
+    for (hipEvent_t& e : ev) {
+        if (!dev->free_events.empty()) { e = dev->free_events.back(); dev->free_events.pop_back(); }
+        else HIP_TRY(hipEventCreate(&e));
+    }
+    t->start = ev[0]; t->stop = ev[1];
+    dev->pending.push_back(TimedDispatch{ev[0], ev[1], kernel, lane});
     return MIRHI_OK;
 }
 
@@ -1254,24 +1337,39 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             const PassParams* dp = c->ws.params + 2 * pi + c->ws.parity;
             uint32_t* big_count = c->ws.big_counts + c->ws.parity;
             c->ws.parity ^= 1u;
-            EventPair ev{};
-            if (dev->profiling) { mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r; }
             // ordered segment: slots of primitives that no draw of the segment covers (a Never draw keeps its ids) must read
             // as "no coverage" -- an all-zero record is a degenerate triangle whose edge functions are negative everywhere
             if (P.ordered_recs && P.ordered_count) HIP_TRY(hipMemsetAsync(P.ordered_recs, 0, (size_t)P.ordered_count * sizeof(TriRec), stream));
-            HIP_TRY(launch_vertex(P, dp, stream));
-            HIP_TRY(launch_geometry(P, dp, stream));
-            if (dev->profiling) {
-                HIP_TRY(hipEventRecord(ev.b, stream));
-                dev->pending[MIRHI_KERNEL_GEOMETRY].push_back(ev);
-                mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r;
+            LaunchTiming tv{}, tg{}, tc{}, tr{};
+            const bool timed = (dev->profiling & MIRHI_PROFILE_TIMING) != 0, counted = (dev->profiling & MIRHI_PROFILE_FRAGMENTS) != 0;
+            if (timed) {
+                mirhi_result r;
+                if (P.vs_total_slots && (r = timing_begin(dev, MIRHI_KERNEL_VERTEX, c->lane, &tv)) != MIRHI_OK) return r;
+                if (P.total_slots && (r = timing_begin(dev, MIRHI_KERNEL_GEOMETRY, c->lane, &tg)) != MIRHI_OK) return r;
             }
-            HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream));
-            if (dev->profiling) {
-                HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending[MIRHI_KERNEL_RASTER].push_back(ev);
-                mirhi_result r = profile_begin(dev, stream, &ev); if (r != MIRHI_OK) return r;
-                HIP_TRY(hipEventRecord(ev.b, stream)); dev->pending_empty.push_back(ev);
+            HIP_TRY(launch_vertex(P, dp, stream, tv));
+            HIP_TRY(launch_geometry(P, dp, stream, tg));
+            const bool has_tiles = P.tile_row_end > P.tile_row_begin && P.tiles_x;
+            const uint32_t* winners = nullptr;
+            if (counted && has_tiles && !P.ordered_recs) {          // (ordered -- blended -- segments are not counted)
+                mirhi_result r;
+                if (timed && (r = timing_begin(dev, MIRHI_KERNEL_FRAGMENT_COUNT, c->lane, &tc)) != MIRHI_OK) return r;
+                HIP_TRY(launch_fragment_count(P, dp, big_count, stream, tc));
+                dev->frag_scopes++;
+                // winners are counted from a primitive-id image: the scope's own if every pixel of it is written (no LOAD),
+                // else the workspace's, cleared to NO_PRIM, through a copy of the parameters -- the raster kernels know nothing
+                // of the statistics
+                if (P.prim_out && !P.color_load) winners = P.prim_out;
+                else {
+                    if ((r = stats_params_for(c)) != MIRHI_OK) return r;
+                    HIP_TRY(hipMemsetAsync(c->ws.stats_prim, 0xFF, (size_t)P.width * P.height * 4, stream));
+                    dp = c->ws.stats_params + (dp - c->ws.params);
+                    winners = c->ws.stats_prim;
+                }
             }
+            if (timed && has_tiles) { mirhi_result r = timing_begin(dev, MIRHI_KERNEL_RASTER, c->lane, &tr); if (r != MIRHI_OK) return r; }
+            HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr));
+            if (winners) HIP_TRY(launch_winner_count(winners, P.width * P.height, dev->frag_stats, stream));
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += P.total_tris;
         }
@@ -1291,6 +1389,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         HIP_TRY(hipEventRecord(fence->event, fstream));
         fence->pending = true; fence->signaled = false;
         fence->cmds.assign(cmds, cmds + cmd_count);
+        fence->deferred = MIRHI_OK; fence->deferred_msg.clear();
     }
     return MIRHI_OK;
 }
@@ -1300,6 +1399,7 @@ extern "C" mirhi_result mirhi_fence_create(mirhi_device* dev, uint32_t signaled,
     mirhi_fence* f = new (std::nothrow) mirhi_fence();
     if (!f) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
     f->dev = dev; f->signaled = signaled != 0;
+    { std::lock_guard<std::mutex> lock(dev->mu); dev->fences.push_back(f); }
     dev->children++;
     *out = f;
     return MIRHI_OK;
@@ -1322,6 +1422,7 @@ static mirhi_result check_status_words(mirhi_device* dev) {
     mirhi_result r = MIRHI_OK;
     for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
     dev->unchecked.clear();
+    if (dev->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = dev->deferred; g_last_error = dev->deferred_msg; } dev->deferred = MIRHI_OK; dev->deferred_msg.clear(); }
     return r;
 }
 static mirhi_result fence_complete(mirhi_fence* f) {
@@ -1336,6 +1437,7 @@ static mirhi_result fence_complete(mirhi_fence* f) {
         }
     }
     f->cmds.clear();
+    if (f->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = f->deferred; g_last_error = f->deferred_msg; } f->deferred = MIRHI_OK; f->deferred_msg.clear(); }
     return r;
 }
 extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
@@ -1388,6 +1490,7 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
     if (f->pending) (void)hipEventSynchronize(f->event);
     if (f->event) (void)hipEventDestroy(f->event);
     if (f->join) (void)hipEventDestroy(f->join);
+    { std::lock_guard<std::mutex> lock(f->dev->mu); auto& v = f->dev->fences; v.erase(std::remove(v.begin(), v.end(), f), v.end()); }
     f->dev->children--;
     delete f;
     return MIRHI_OK;
@@ -1399,51 +1502,29 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
 extern "C" mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable) {
     NULL_CHECK(dev, "device");
     std::lock_guard<std::mutex> lock(dev->mu);
-    if (enable && dev->event_overhead_ms == 0.0) {
-        // An event pair costs ~4-5 us of stream time on this part even around nothing (tools/microbench/evt.hip).
-        // Calibrate it once and subtract it per launch so reported kernel durations agree with rocprofv3.
-        HIP_TRY(hipSetDevice(dev->ordinal));
-        const int n = 64;
-        std::vector<hipEvent_t> ev(2 * n);
-        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipStreamSynchronize(dev->stream));
-        for (int i = 0; i < n; i++) { HIP_TRY(hipEventRecord(ev[2 * i], dev->stream)); HIP_TRY(hipEventRecord(ev[2 * i + 1], dev->stream)); }
-        HIP_TRY(hipStreamSynchronize(dev->stream));
-        double sum = 0.0;
-        for (int i = 8; i < n; i++) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); sum += ms; }
-        dev->event_overhead_ms = sum / (n - 8);
-        if (getenv("MIRHI_DEBUG")) fprintf(stderr, "[mirhi] calibrated empty event pair: %.3f us\n", 1e3 * dev->event_overhead_ms);
-        for (auto& e : ev) (void)hipEventDestroy(e);
-    }
-    dev->profiling = enable != 0;
+    dev->profiling = enable & (MIRHI_PROFILE_TIMING | MIRHI_PROFILE_FRAGMENTS);
     return MIRHI_OK;
 }
+// Reads the timed dispatches back: duration = elapsed(start, stop) of the dispatch's own pair; position on the timeline =
+// distance of its end from the end of the first dispatch since the last reset (hipEventElapsedTime between the stop events of
+// two dispatches is the difference of their completion timestamps, whichever streams they ran on).
 static mirhi_result drain_events(mirhi_device* dev) {
     HIP_TRY(hipSetDevice(dev->ordinal));
-    for (int k = 0; k < MIRHI_KERNEL_COUNT; k++) {
-        for (auto& p : dev->pending[k]) {
-            HIP_TRY(hipEventSynchronize(p.b));
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
-            dev->total_ms[k] += ms; dev->launches[k]++;
-            dev->free_events.push_back(p);
-        }
-        dev->pending[k].clear();
-    }
-    for (auto& p : dev->pending_empty) {
-        HIP_TRY(hipEventSynchronize(p.b));
+    for (TimedDispatch& p : dev->pending) {
+        HIP_TRY(hipEventSynchronize(p.stop));
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
-        dev->empty_ms += ms; dev->empty_n++;
-        dev->free_events.push_back(p);
+        HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+        bool keep_stop = false;
+        double end_ms;
+        if (!dev->base_stop) { dev->base_stop = p.stop; dev->base_end_ms = ms; end_ms = ms; keep_stop = true; }
+        else { float rel = 0.0f; HIP_TRY(hipEventElapsedTime(&rel, dev->base_stop, p.stop)); end_ms = dev->base_end_ms + rel; }
+        if (p.kernel < MIRHI_KERNEL_COUNT) { dev->total_ms[p.kernel] += ms; dev->launches[p.kernel]++; }
+        if (dev->timeline.size() < (1u << 20)) dev->timeline.push_back(mirhi_dispatch_time{p.kernel, p.lane, (end_ms - ms) * 1e3, end_ms * 1e3});
+        dev->free_events.push_back(p.start);
+        if (!keep_stop) dev->free_events.push_back(p.stop);
     }
-    dev->pending_empty.clear();
+    dev->pending.clear();
     return MIRHI_OK;
-}
-// Stream time of an event pair around nothing: the in-situ samples of this measurement window when there are any (they saw
-// the same clocks and queue state as the kernel pairs), else the one-off calibration of mirhi_device_set_profiling.
-static double event_overhead(const mirhi_device* dev) {
-    return dev->empty_n ? dev->empty_ms / (double)dev->empty_n : dev->event_overhead_ms;
 }
 extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches) {
     NULL_CHECK(dev, "device");
@@ -1451,34 +1532,206 @@ extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel
     std::lock_guard<std::mutex> lock(dev->mu);
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
-    if (total_ms) {
-        const double corrected = dev->total_ms[kernel] - event_overhead(dev) * (double)dev->launches[kernel];
-        *total_ms = corrected > 0.0 ? corrected : 0.0;
-    }
+    if (total_ms) *total_ms = dev->total_ms[kernel];
     if (launches) *launches = dev->launches[kernel];
     return MIRHI_OK;
 }
-extern "C" mirhi_result mirhi_device_event_overhead(mirhi_device* dev, double* overhead_ms, uint64_t* samples) {
-    NULL_CHECK(dev, "device");
+extern "C" mirhi_result mirhi_device_timeline(mirhi_device* dev, mirhi_dispatch_time* out, uint32_t capacity, uint32_t* count) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(count, "count");
     std::lock_guard<std::mutex> lock(dev->mu);
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
-    if (overhead_ms) *overhead_ms = event_overhead(dev);
-    if (samples) *samples = dev->empty_n;
+    *count = (uint32_t)dev->timeline.size();
+    if (out) for (uint32_t i = 0; i < capacity && i < *count; i++) out[i] = dev->timeline[i];
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_fragment_stats(mirhi_device* dev, uint64_t* shaded_pixels, uint64_t* covered_fragments, uint64_t* scopes) {
+    NULL_CHECK(dev, "device");
+    { mirhi_result r0 = sync_all_lanes(dev); if (r0 != MIRHI_OK) return r0; }
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpy(v, dev->frag_stats, sizeof v, hipMemcpyDeviceToHost));
+    if (shaded_pixels) *shaded_pixels = v[0];
+    if (covered_fragments) *covered_fragments = v[1];
+    if (scopes) { std::lock_guard<std::mutex> lock(dev->mu); *scopes = dev->frag_scopes; }
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
     NULL_CHECK(dev, "device");
+    { mirhi_result r0 = sync_all_lanes(dev); if (r0 != MIRHI_OK) return r0; }
     std::lock_guard<std::mutex> lock(dev->mu);
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
     for (int k = 0; k < MIRHI_KERNEL_COUNT; k++) { dev->total_ms[k] = 0; dev->launches[k] = 0; }
-    dev->empty_ms = 0.0; dev->empty_n = 0;
+    dev->timeline.clear();
+    if (dev->base_stop) { dev->free_events.push_back(dev->base_stop); dev->base_stop = nullptr; }
+    dev->base_end_ms = 0.0;
+    dev->frag_scopes = 0;
+    HIP_TRY(hipMemset(dev->frag_stats, 0, 2 * sizeof(unsigned long long)));
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out) {
     NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
     std::lock_guard<std::mutex> lock(dev->mu);
     *out = dev->stats;
+    return MIRHI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: exchange of the finished bands over RCCL
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+// The library a process already holds (PyTorch ships its own librccl.so.1) is found by its soname; otherwise the ROCm install.
+mirhi_result rccl_load(Rccl** out) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    Rccl& R = g_rccl;
+    if (!R.handle) {
+        const char* env = getenv("MIRHI_RCCL_LIBRARY");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (R.handle) break;
+            R.error = dlerror();
+        }
+        if (!R.handle) return fail(MIRHI_ERR_LOADING, "Loading error: librccl not found (%s); the tile-row split needs RCCL", R.error.c_str());
+        bool ok = true;
+#define MIRHI_RCCL_SYM(field, name) do { R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.handle, name)); if (!R.field) { ok = false; R.error = name; } } while (0)
+        MIRHI_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); MIRHI_RCCL_SYM(CommInitRank, "ncclCommInitRank"); MIRHI_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        MIRHI_RCCL_SYM(CommCount, "ncclCommCount"); MIRHI_RCCL_SYM(GroupStart, "ncclGroupStart"); MIRHI_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        MIRHI_RCCL_SYM(Send, "ncclSend"); MIRHI_RCCL_SYM(Recv, "ncclRecv"); MIRHI_RCCL_SYM(Broadcast, "ncclBroadcast");
+        MIRHI_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef MIRHI_RCCL_SYM
+        if (!ok) { dlclose(R.handle); R.handle = nullptr; return fail(MIRHI_ERR_LOADING, "Loading error: librccl lacks %s", R.error.c_str()); }
+    }
+    *out = &R;
+    return MIRHI_OK;
+}
+}  // namespace
+
+struct mirhi_comm {
+    mirhi_device* dev;
+    Rccl* rccl;
+    ncclComm_t comm;
+    uint32_t rank, world, counted;
+    // Every exchange runs on ONE stream of the communicator's own, whatever queue lane rendered the frame: RCCL sees a single,
+    // totally ordered stream, and frames in flight on other lanes keep rendering while a band exchange is under way.
+    hipStream_t stream;
+    hipEvent_t ready, done;       // lane -> exchange stream, exchange stream -> lane
+};
+#define RCCL_TRY(R, expr)                                                                                     \
+    do {                                                                                                      \
+        ncclResult_t r__ = (expr);                                                                            \
+        if (r__ != ncclSuccess) return fail(MIRHI_ERR_DEVICE, "Vulkan error: RCCL: %s (%s)", (R)->GetErrorString(r__), #expr); \
+    } while (0)
+
+extern "C" mirhi_result mirhi_comm_unique_id(uint8_t* id) {
+    NULL_CHECK(id, "id");
+    static_assert(MIRHI_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    Rccl* R = nullptr;
+    mirhi_result r = rccl_load(&R);
+    if (r != MIRHI_OK) return r;
+    ncclUniqueId u;
+    RCCL_TRY(R, R->GetUniqueId(&u));
+    memcpy(id, u.internal, MIRHI_COMM_ID_BYTES);
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_comm_create(mirhi_device* dev, const uint8_t* id, uint32_t rank, uint32_t world, mirhi_comm** out) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(id, "id"); NULL_CHECK(out, "out");
+    *out = nullptr;
+    if (world == 0 || rank >= world) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: communicator rank %u of %u", rank, world);
+    Rccl* R = nullptr;
+    mirhi_result r = rccl_load(&R);
+    if (r != MIRHI_OK) return r;
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    ncclUniqueId u;
+    memcpy(u.internal, id, MIRHI_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(R, R->CommInitRank(&comm, (int)world, u, (int)rank));
+    int counted = 0;
+    RCCL_TRY(R, R->CommCount(comm, &counted));
+    mirhi_comm* c = new (std::nothrow) mirhi_comm{dev, R, comm, rank, world, (uint32_t)counted, nullptr, nullptr, nullptr};
+    if (!c) { (void)R->CommDestroy(comm); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed"); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); (void)R->CommDestroy(comm); delete c;
+        return fail(MIRHI_ERR_DEVICE, "Vulkan error: stream / event creation for the band exchange failed");
+    }
+    dev->split_rank = rank; dev->split_world = world;
+    dev->children++;
+    *out = c;
+    return MIRHI_OK;
+}
+extern "C" uint32_t mirhi_comm_world(const mirhi_comm* comm) { return comm ? comm->counted : 0; }
+extern "C" uint32_t mirhi_comm_rank(const mirhi_comm* comm) { return comm ? comm->rank : 0; }
+
+extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_image* frame, mirhi_cmd* after, mirhi_gather_algo algo) {
+    NULL_CHECK(comm, "comm"); NULL_CHECK(frame, "frame");
+    mirhi_device* dev = comm->dev;
+    if (frame->dev != dev || (after && after->dev != dev)) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: frame / command buffer belongs to another device");
+    if (algo != MIRHI_GATHER_DIRECT && algo != MIRHI_GATHER_BROADCAST) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown gather algorithm %d", (int)algo);
+    if (dev->split_world != comm->world || dev->split_rank != comm->rank)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
+    HIP_TRY(hipSetDevice(dev->ordinal));
+    hipStream_t lane = dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
+    hipStream_t stream = comm->stream;
+    const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;
+    const size_t row_bytes = (size_t)frame->width * format_bpp(frame->format);
+    Rccl* R = comm->rccl;
+    auto band = [&](uint32_t r, size_t* off, size_t* bytes) {
+        uint32_t t0, t1;
+        band_tile_rows(r, comm->world, tiles_y, &t0, &t1);
+        size_t p0 = (size_t)t0 * TILE, p1 = (size_t)t1 * TILE;
+        if (p0 > frame->height) p0 = frame->height;
+        if (p1 > frame->height) p1 = frame->height;
+        *off = p0 * row_bytes; *bytes = (p1 - p0) * row_bytes;
+    };
+    size_t my_off, my_bytes;
+    band(comm->rank, &my_off, &my_bytes);
+    if (comm->world == 1) return MIRHI_OK;
+    HIP_TRY(hipEventRecord(comm->ready, lane));              // the exchange starts behind the frame's raster kernel ...
+    HIP_TRY(hipStreamWaitEvent(stream, comm->ready, 0));
+    RCCL_TRY(R, R->GroupStart());
+    for (uint32_t r = 0; r < comm->world; r++) {
+        size_t off, bytes;
+        band(r, &off, &bytes);
+        if (algo == MIRHI_GATHER_BROADCAST) {
+            if (bytes) RCCL_TRY(R, R->Broadcast(frame->ptr + off, frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream));
+            continue;
+        }
+        if (r == comm->rank) continue;
+        if (my_bytes) RCCL_TRY(R, R->Send(frame->ptr + my_off, my_bytes, ncclUint8, (int)r, comm->comm, stream));
+        if (bytes) RCCL_TRY(R, R->Recv(frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream));
+    }
+    RCCL_TRY(R, R->GroupEnd());
+    HIP_TRY(hipEventRecord(comm->done, stream));             // ... and whatever follows on the lane starts behind the exchange
+    HIP_TRY(hipStreamWaitEvent(lane, comm->done, 0));
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_comm_destroy(mirhi_comm* comm) {
+    NULL_CHECK(comm, "comm");
+    (void)hipSetDevice(comm->dev->ordinal);
+    (void)sync_all_lanes(comm->dev);
+    (void)hipStreamSynchronize(comm->stream);
+    (void)comm->rccl->CommDestroy(comm->comm);
+    (void)hipEventDestroy(comm->ready); (void)hipEventDestroy(comm->done); (void)hipStreamDestroy(comm->stream);
+    comm->dev->children--;
+    delete comm;
     return MIRHI_OK;
 }

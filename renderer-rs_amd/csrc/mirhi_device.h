@@ -133,6 +133,8 @@ struct PassParams {
     uint32_t ord_depth_test, ord_depth_write, ord_depth_op;
     uint32_t blend[8];                // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
     uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
+    unsigned long long* frag_stats;   // device counters of the statistics pass (never touched by geometry / raster kernels): [0] pixels that
+                                      // ran a fragment program (winners of the depth resolve), [1] fragments covered before the depth test
 };
 
 // Kernel arguments passed by value next to the PassParams pointer: what a wave needs before anything else, so that its

@@ -18,6 +18,7 @@
 // binary32 {+,-,*,/} in the order fixed by DESIGN.md "Pipeline specification"; this file is
 // compiled with -ffp-contract=off so results are bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -30,6 +31,7 @@ namespace mirhi {
 #include "mirhi_geometry.hip.h"
 #include "mirhi_shading.hip.h"
 #include "mirhi_raster.hip.h"
+#include "mirhi_stats.hip.h"
 #include "mirhi_ordered.hip.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -39,58 +41,80 @@ hipError_t upload_srgb_lut(const float* lut) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_lut), lut, 256 * sizeof(float), 0, hipMemcpyHostToDevice);
 }
 
-hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream) {
+// A plain launch, or -- when the caller wants the dispatch timed -- one with an event pair attached to the dispatch itself.
+#define MIRHI_LAUNCH(kernel, grid, block, stream, t, ...)                                                               \
+    do {                                                                                                                \
+        if ((t).start) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                           \
+    } while (0)
+
+hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
     if (P.vs_total_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), 0, stream, dev_params);
+    MIRHI_LAUNCH(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), stream, t, dev_params);
     return hipGetLastError();
 }
 
-hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream) {
+hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t blocks = P.total_slots / GEOM_THREADS;
     const GeometryHead H = {P.draws, P.num_draws};
     // (more waves than the chip holds at five per SIMD: the occupancy-oriented variant)
-    if (blocks > 5u * 1024u) hipLaunchKernelGGL(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
-    else hipLaunchKernelGGL(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), 0, stream, dev_params, H);
+    if (blocks > 5u * 1024u) MIRHI_LAUNCH(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
+    else MIRHI_LAUNCH(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
     return hipGetLastError();
 }
 
 template <int KEYED, int TP, int TEAMS = 1>
-static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream) {
+static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream, LaunchTiming t) {
     const dim3 block(RASTER_THREADS * TEAMS);
     if (TEAMS > 1) {            // only the pure mesh variants exist with two teams (launch_raster checks)
-        if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP, TEAMS>), grid, block, 0, stream, P, H);
-        else hipLaunchKernelGGL((raster_kernel<4, KEYED, TP, TEAMS>), grid, block, 0, stream, P, H);
+        if (programs == 2) MIRHI_LAUNCH((raster_kernel<2, KEYED, TP, TEAMS>), grid, block, stream, t, P, H);
+        else MIRHI_LAUNCH((raster_kernel<4, KEYED, TP, TEAMS>), grid, block, stream, t, P, H);
         return;
     }
-    if (programs == 2) hipLaunchKernelGGL((raster_kernel<2, KEYED, TP>), grid, block, 0, stream, P, H);
-    else if (programs == 3) hipLaunchKernelGGL((raster_kernel<3, KEYED, TP>), grid, block, 0, stream, P, H);
-    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel<4, KEYED, TP>), grid, block, 0, stream, P, H);
-    else hipLaunchKernelGGL((raster_kernel<1, KEYED, TP>), grid, block, 0, stream, P, H);
+    if (programs == 2) MIRHI_LAUNCH((raster_kernel<2, KEYED, TP>), grid, block, stream, t, P, H);
+    else if (programs == 3) MIRHI_LAUNCH((raster_kernel<3, KEYED, TP>), grid, block, stream, t, P, H);
+    else if (programs >= 4) MIRHI_LAUNCH((raster_kernel<4, KEYED, TP>), grid, block, stream, t, P, H);
+    else MIRHI_LAUNCH((raster_kernel<1, KEYED, TP>), grid, block, stream, t, P, H);
 }
 
-hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream) {
+hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
     if (P.ordered_recs) {           // ordered segment: fragments in primitive order (blending)
         const RasterHead HO = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.bin_cap, 0u};
         const dim3 og(P.tiles_x, rows), ob(ORDERED_THREADS);
-        if (programs == 2) hipLaunchKernelGGL(ordered_kernel<2>, og, ob, 0, stream, dev_params, HO);
-        else if (programs == 3) hipLaunchKernelGGL(ordered_kernel<3>, og, ob, 0, stream, dev_params, HO);
-        else if (programs >= 4) hipLaunchKernelGGL(ordered_kernel<4>, og, ob, 0, stream, dev_params, HO);
-        else hipLaunchKernelGGL(ordered_kernel<1>, og, ob, 0, stream, dev_params, HO);
+        if (programs == 2) MIRHI_LAUNCH(ordered_kernel<2>, og, ob, stream, t, dev_params, HO);
+        else if (programs == 3) MIRHI_LAUNCH(ordered_kernel<3>, og, ob, stream, t, dev_params, HO);
+        else if (programs >= 4) MIRHI_LAUNCH(ordered_kernel<4>, og, ob, stream, t, dev_params, HO);
+        else MIRHI_LAUNCH(ordered_kernel<1>, og, ob, stream, t, dev_params, HO);
         return hipGetLastError();
     }
     const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     const RasterHead H = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride};
-    if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream);          // (the host keeps tp_max_area = 0 for predicate scopes)
+    if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream, t);          // (the host keeps tp_max_area = 0 for predicate scopes)
     else if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) {
-        if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream);
+        if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream, t);
     }
-    else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream); }
-    else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream); }
+    else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream, t); }
+    else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream, t); }
+    return hipGetLastError();
+}
+
+hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
+    const uint32_t rows = P.tile_row_end - P.tile_row_begin;
+    if (rows == 0 || P.tiles_x == 0 || P.ordered_recs) return hipSuccess;
+    const RasterHead H = {P.bin_count, P.bin_recs, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride};
+    MIRHI_LAUNCH(fragment_count_kernel, dim3(P.tiles_x, rows), dim3(RASTER_THREADS), stream, t, dev_params, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream) {
+    if (!pixels) return hipSuccess;
+    const uint32_t blocks = (pixels + RASTER_THREADS * 16u - 1u) / (RASTER_THREADS * 16u);
+    hipLaunchKernelGGL(winner_count_kernel, dim3(blocks), dim3(RASTER_THREADS), 0, stream, prim, pixels, stats);
     return hipGetLastError();
 }
 

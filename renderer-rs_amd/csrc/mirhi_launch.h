@@ -5,11 +5,22 @@
 #include "mirhi_device.h"
 
 namespace mirhi {
-// P: host copy (launch geometry); dev_params: the same parameters in device memory, read by the kernels
-hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream);      // no-op unless the scope uses MODEL programs
-hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream);
+// P: host copy (launch geometry); dev_params: the same parameters in device memory, read by the kernels.
+// Timing: a non-null event pair is attached to the dispatch itself (hipExtLaunchKernelGGL): hipEventElapsedTime(start, stop)
+// is then the kernel's own begin -> end on the GPU clock, what rocprofv3 --kernel-trace reports, with no event-record
+// commands of its own in the stream.  Null events: a plain launch.
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; };
+hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
+hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
-hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream);  // programs: bit0 TRIANGLE, bit1 MODEL / MODEL_FULL, bit2 MODEL_PBR
+// programs: bit0 TRIANGLE, bit1 MODEL / MODEL_FULL, bit2 MODEL_PBR
+hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t = {});
+// profiling only: counts the fragments the scope's binned triangles cover (before any depth test) into P.frag_stats[1];
+// runs between the geometry and the raster kernel (the raster kernel re-arms the bin counters)
+hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t = {});
+// statistics pass only: adds the number of pixels of `prim` (the scope's primitive-id image, NO_PRIM where nothing won) that hold
+// a primitive to stats[0]
+hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream);
 // sRGB byte -> linear table of the current device (R8G8B8A8_SRGB textures); 256 floats
 hipError_t upload_srgb_lut(const float* lut);
 }  // namespace mirhi

@@ -212,6 +212,10 @@ def _load(path: str, images: bool) -> Model:
             tan = _read_accessor(doc, buffers, attrs["TANGENT"]).astype(np.float32) if "TANGENT" in attrs else np.tile(np.float32([1, 0, 0, 1]), (n, 1))
             idx = (_read_accessor(doc, buffers, prim["indices"]).reshape(-1).astype(np.uint32) if "indices" in prim
                    else np.arange(n, dtype=np.uint32))
+            if idx.size and int(idx.max()) >= n:
+                # an index beyond the primitive's vertices would make the GPU's vertex fetch read out of bounds (a device fault,
+                # not an error code): refuse the asset here, as host/gltf.hpp does
+                raise ResourceError(f"Index {int(idx.max())} out of range for a primitive with {n} vertices")
             model.aabb_min = np.minimum(model.aabb_min, pos.min(axis=0))
             model.aabb_max = np.maximum(model.aabb_max, pos.max(axis=0))
             model.meshes.append(Mesh(pos, nrm, uv, tan, idx, prim.get("material")))

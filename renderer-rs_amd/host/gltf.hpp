@@ -235,7 +235,13 @@ private:
                 if (attrs->has("NORMAL")) { const auto v = floats(doc, buffers, (size_t)attrs->at("NORMAL").num, 3); for (size_t i = 0; i < n && 3 * i + 2 < v.size(); i++) out.normals[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]}; }
                 if (attrs->has("TEXCOORD_0")) { const auto v = floats(doc, buffers, (size_t)attrs->at("TEXCOORD_0").num, 2); for (size_t i = 0; i < n && 2 * i + 1 < v.size(); i++) out.tex_coords[i] = {v[2 * i], v[2 * i + 1]}; }
                 if (attrs->has("TANGENT")) { const auto v = floats(doc, buffers, (size_t)attrs->at("TANGENT").num, 4); for (size_t i = 0; i < n && 4 * i + 3 < v.size(); i++) out.tangents[i] = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}; }
-                if (prim.has("indices")) out.indices = indices(doc, buffers, (size_t)prim.at("indices").num);
+                if (prim.has("indices")) {
+                    out.indices = indices(doc, buffers, (size_t)prim.at("indices").num);
+                    // an index beyond the primitive's vertices would make the GPU's vertex fetch read out of bounds (a device fault,
+                    // not an error code): refuse the asset here
+                    for (const uint32_t ix : out.indices)
+                        if (ix >= n) throw ResourceError("Index " + std::to_string(ix) + " out of range for a primitive with " + std::to_string(n) + " vertices");
+                }
                 else { out.indices.resize(n); for (size_t i = 0; i < n; i++) out.indices[i] = (uint32_t)i; }
                 if (prim.has("material")) out.material_index = (size_t)prim.at("material").num;
                 model.meshes.push_back(std::move(out));

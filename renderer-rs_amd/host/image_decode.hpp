@@ -92,14 +92,19 @@ struct Huff {                           // canonical code, LSB-first lookup: 10-
     }
 };
 
-inline void inflate(const uint8_t* src, size_t len, std::vector<uint8_t>& out, size_t expected) {
+// Returns false if the stream holds more than `expected` bytes: output stops there (the surplus is ignored, as libpng and
+// the `png` crate do) and the caller skips the checksum, which covers the whole stream.
+inline bool inflate(const uint8_t* src, size_t len, std::vector<uint8_t>& out, size_t expected) {
     static const uint16_t LBASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     static const uint8_t LEXT[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
     static const uint16_t DBASE[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
     static const uint8_t DEXT[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
     static const uint8_t ORDER[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
     BitReader br(src, len);
-    out.clear(); out.reserve(expected);
+    // deflate expands at most 1032:1, so a short stream cannot justify a large reservation whatever the header claims; and
+    // nothing is produced beyond what the caller expects (a 60-byte PNG must not drive multi-GiB allocations)
+    out.clear(); out.reserve(expected < len * 1032 + 64 ? expected : len * 1032 + 64);
+    auto room = [&](size_t more) { return out.size() + more <= expected; };
     static thread_local Huff lit, dist;
     bool last = false;
     while (!last) {
@@ -109,7 +114,7 @@ inline void inflate(const uint8_t* src, size_t len, std::vector<uint8_t>& out, s
             br.align_byte();
             const uint32_t n = br.take(16), nn = br.take(16);
             if ((n ^ nn) != 0xFFFF) throw ImageError("inflate: stored block length check failed");
-            for (uint32_t i = 0; i < n; i++) out.push_back((uint8_t)br.take(8));
+            for (uint32_t i = 0; i < n; i++) { if (!room(1)) return false; out.push_back((uint8_t)br.take(8)); }
             continue;
         }
         if (type == 3) throw ImageError("inflate: reserved block type");
@@ -146,7 +151,7 @@ inline void inflate(const uint8_t* src, size_t len, std::vector<uint8_t>& out, s
         }
         for (;;) {
             int sym = lit.decode(br);
-            if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+            if (sym < 256) { if (!room(1)) return false; out.push_back((uint8_t)sym); continue; }
             if (sym == 256) break;
             sym -= 257;
             if (sym >= 29) throw ImageError("inflate: invalid length symbol");
@@ -156,11 +161,14 @@ inline void inflate(const uint8_t* src, size_t len, std::vector<uint8_t>& out, s
             const size_t d = DBASE[ds] + br.take(DEXT[ds]);
             if (d > out.size()) throw ImageError("inflate: distance reaches before the start of the output");
             const size_t start = out.size() - d;
-            out.resize(out.size() + length);
+            const size_t fits = room(length) ? length : expected - out.size();
+            out.resize(out.size() + fits);
             uint8_t* o = out.data();
-            for (size_t k = 0; k < length; k++) o[start + d + k] = o[start + k];
+            for (size_t k = 0; k < fits; k++) o[start + d + k] = o[start + k];
+            if (fits < length) return false;
         }
     }
+    return true;
 }
 
 inline uint32_t adler32(const uint8_t* p, size_t n) {
@@ -177,7 +185,7 @@ inline void zlib_decompress(const uint8_t* src, size_t len, std::vector<uint8_t>
     if (len < 6) throw ImageError("zlib: stream too short");
     if ((src[0] & 0x0F) != 8 || ((src[0] << 8 | src[1]) % 31) != 0) throw ImageError("zlib: bad header");
     if (src[1] & 0x20) throw ImageError("zlib: preset dictionary not allowed in PNG");
-    inflate(src + 2, len - 6, out, expected);
+    if (!inflate(src + 2, len - 6, out, expected)) return;
     const uint32_t want = (uint32_t)src[len - 4] << 24 | (uint32_t)src[len - 3] << 16 | (uint32_t)src[len - 2] << 8 | src[len - 1];
 #ifndef MIRHI_IMAGE_FUZZ_SKIP_CHECKS
     if (adler32(out.data(), out.size()) != want) throw ImageError("zlib: Adler-32 mismatch");

@@ -143,6 +143,13 @@ static void gpu_tests() {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 2 && std::strcmp(argv[1], "--load-gltf") == 0) {      // exit 0 = loaded, 3 = ResourceError (message on stdout)
+        try {
+            const resources::Model m = resources::Model::load(argv[2]);
+            std::printf("loaded: %zu meshes, %zu vertices, %zu triangles\n", m.meshes.size(), (size_t)m.total_vertices(), (size_t)m.total_triangles());
+            return 0;
+        } catch (const resources::ResourceError& e) { std::printf("ResourceError: %s\n", e.what()); return 3; }
+    }
     cpu_tests();
     if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) {
         try { gpu_tests(); } catch (const RhiError& e) { std::printf("FAIL: RhiError %s\n", e.what()); failures++; }

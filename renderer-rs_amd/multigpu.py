@@ -58,3 +58,24 @@ def all_gather_bands(frame, rank: int, world: int, group=None, via_host: bool = 
         for c, o in zip(chunks, outs):
             c.copy_(o)
     return frame
+
+
+def exchange_bands_direct(frame, height: int, rank: int, world: int, group=None):
+    """The MIRHI_GATHER_DIRECT pattern of mirhi_comm_all_gather_bands (csrc/mirhi_api.hip) on torch.distributed: every rank
+    sends its band straight to every peer and receives theirs, one batch of point-to-point transfers, in place on an UNPADDED
+    (height, W, C) frame -- bands may differ in size (the last one is short when the tile rows do not divide)."""
+    import torch.distributed as dist
+    b0, e0 = band_rows(height, rank, world)
+    ops = []
+    for r in range(world):
+        if r == rank:
+            continue
+        b, e = band_rows(height, r, world)
+        if e0 > b0:
+            ops.append(dist.P2POp(dist.isend, frame[b0:e0], r, group=group))
+        if e > b:
+            ops.append(dist.P2POp(dist.irecv, frame[b:e], r, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return frame

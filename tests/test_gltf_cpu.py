@@ -88,6 +88,38 @@ def test_documents_that_lie_about_themselves_are_resource_errors(mirhi, tmp_path
     assert gltf.load(str(p)).meshes[0].vertex_count == 3
 
 
+def _indexed_doc(indices):
+    import base64
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    idx = np.asarray(indices, dtype=np.uint16)
+    blob = pos.tobytes() + idx.tobytes()
+    uri = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    return {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob), "uri": uri}],
+            "bufferViews": [{"buffer": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": idx.nbytes}],
+            "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                          {"bufferView": 1, "componentType": 5123, "count": int(idx.size), "type": "SCALAR"}],
+            "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}]}
+
+
+def test_index_beyond_the_vertex_count_is_a_resource_error(mirhi, tmp_path):
+    """an index >= vertex count would be a GPU memory fault in the vertex fetch, not an error code -- both loaders
+    (gltf.py and host/gltf.hpp through test_host) refuse the asset."""
+    import subprocess
+    from renderer_rs_amd import gltf
+    good, bad = tmp_path / "good.gltf", tmp_path / "bad.gltf"
+    good.write_text(json.dumps(_indexed_doc([0, 1, 2, 2, 1, 0])))
+    bad.write_text(json.dumps(_indexed_doc([0, 1, 3])))
+    assert gltf.load(str(good)).meshes[0].indices.tolist() == [0, 1, 2, 2, 1, 0]
+    with pytest.raises(gltf.ResourceError, match="out of range"):
+        gltf.load(str(bad))
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "renderer-rs_amd", "host", "test_host")
+    if os.path.exists(host):
+        ok = subprocess.run([host, "--load-gltf", str(good)], capture_output=True, text=True)
+        assert ok.returncode == 0, ok.stdout + ok.stderr
+        r = subprocess.run([host, "--load-gltf", str(bad)], capture_output=True, text=True)
+        assert r.returncode == 3 and "out of range" in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
 def test_dancer_scene_renders_with_oracle(oracle, scenes):
     s = scenes.gltf_model(DANCER, 320, 180)
     assert s.num_triangles == 17210

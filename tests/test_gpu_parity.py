@@ -295,3 +295,89 @@ def test_mip_chain_matches_the_stated_rule(mirhi, device, scenes, shape):
     assert np.array_equal(got, want)
     view.destroy()
     t.destroy()
+
+
+# ---- the path bench.py times ---------------------------------------------------------
+# B8G8R8A8_SRGB target, no primitive-id image, no depth image: raster_kernel<1,0,0,1> takes the flat-colour fast exit
+# (packed colours from the geometry kernel, 32-bit-offset stores; interior-tile and edge-tile branches), with several
+# command buffers in flight on separate queue lanes.  Spec: crates/rhi/src/swapchain.rs:561-570 (target format),
+# crates/renderer/src/renderer.rs:479-488 (clear / store).
+def _bench_like_frames(mirhi, scene, lanes, frames, ordinal=0):
+    """Renders `frames` frames round-robin over `lanes` command buffers exactly as bench.py does; returns every target."""
+    dev = mirhi.Device(ordinal)
+    dev.set_queue_lanes(lanes)
+    shared = {}
+
+    def wrap_shared(device, usage, arr):     # geometry is uploaded once and shared by all frames in flight
+        key = (usage, arr.ctypes.data, arr.size)
+        if key not in shared:
+            shared[key] = mirhi.Buffer.new_with_data(device, usage, arr)
+        return shared[key]
+
+    slots = [mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB, wrap_buffers=wrap_shared) for _ in range(lanes)]
+    for f in range(frames):
+        slots[f % lanes].render()
+    dev.wait_idle()
+    outs = [s.color.read() for s in slots]
+    seen = set()
+    for s in slots:
+        s.objs = [o for o in s.objs if not (id(o) in seen or seen.add(id(o)))]
+        s.destroy()
+    dev.destroy()
+    return outs
+
+
+@pytest.mark.parametrize("shape", ["c2_1080p", "edge_1900x1070", "small_640x360", "tiny_33x31"])
+def test_bench_path_pixels(mirhi, oracle, device, scenes, shape):
+    scene = {"c2_1080p": lambda: scenes.random_triangles(),
+             "edge_1900x1070": lambda: scenes.random_triangles(10000, 1900, 1070, seed=0x5EED0102),
+             "small_640x360": lambda: scenes.random_triangles(2000, 640, 360, seed=9),
+             "tiny_33x31": lambda: scenes.random_triangles(40, 33, 31, seed=5, rmin=2, rmax=12)}[shape]()
+    ref = oracle.render(scene, want_bgra8=True)
+    outs = _bench_like_frames(mirhi, scene, lanes=4, frames=12)
+    # the same scene through the general resolve (a bound primitive-id image disables the fast exit)
+    res = mirhi.SceneResources(device, scene, mirhi.Format.B8G8R8A8_SRGB, want_prim=True)
+    res.render()
+    general = res.read()
+    res.destroy()
+    assert np.array_equal(general["prim"], ref["prim"])
+    for i, out in enumerate(outs):
+        d = np.abs(out.astype(np.int32) - ref["bgra8"].astype(np.int32))
+        assert d.max() <= 1, f"{shape} lane {i}: sRGB8 differs from the oracle by {d.max()} LSB at {np.argwhere(d > 1)[:1]}"
+        assert np.array_equal(out, general["color"]), f"{shape} lane {i}: fast exit differs from the general resolve at {np.argwhere(out != general['color'])[:1]}"
+
+
+def test_bench_path_load_second_scope(mirhi, oracle, device, scenes):
+    """A second scope with LOAD_OP_LOAD on the same sRGB8 target (fast exit, `color_load` branch): pixels the second scene
+    does not cover keep the first scene's colour."""
+    a = scenes.random_triangles(1500, 700, 390, seed=21)
+    b = scenes.random_triangles(300, 700, 390, seed=22, rmin=4, rmax=30)
+    ra, rb = oracle.render(a, want_bgra8=True), oracle.render(b, want_bgra8=True)
+    first = mirhi.SceneResources(device, a, mirhi.Format.B8G8R8A8_SRGB)
+    second = mirhi.SceneResources(device, b, mirhi.Format.B8G8R8A8_SRGB, color_image=first.color, color_load_op=mirhi.LoadOp.LOAD)
+    for _ in range(3):
+        first.render()
+        second.render()
+    out = second.read()["color"]
+    covered = (rb["prim"] != 0xFFFFFFFF)[..., None]
+    want = np.where(covered, rb["bgra8"], ra["bgra8"]).astype(np.int32)
+    assert np.abs(out.astype(np.int32) - want).max() <= 1
+    second.color = None          # shared with `first`
+    second.destroy()
+    first.destroy()
+
+
+def test_bench_path_mixed_flat_and_smooth(mirhi, oracle, device, scenes):
+    """Waves that hold a covered pixel WITHOUT a flat colour (smooth-shaded triangles) must leave the fast exit for the general
+    loop; flat and smooth triangles are mixed in one draw."""
+    scene = scenes.random_triangles(1200, 640, 360, seed=31)
+    v = scene.draws[0].vertices.copy()
+    rng = np.random.default_rng(7)
+    smooth = rng.random(len(v) // 3) < 0.3                      # 30 % of the triangles get three different vertex colours
+    cols = v.reshape(-1, 3, 6)[:, :, 3:6]
+    cols[smooth] = rng.random((int(smooth.sum()), 3, 3), dtype=np.float32)
+    scene.draws[0].vertices = v
+    ref = oracle.render(scene, want_bgra8=True)
+    outs = _bench_like_frames(mirhi, scene, lanes=2, frames=4)
+    for out in outs:
+        assert np.abs(out.astype(np.int32) - ref["bgra8"].astype(np.int32)).max() <= 1

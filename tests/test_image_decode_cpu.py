@@ -219,6 +219,24 @@ def test_png_errors_are_reported_not_decoded():
     assert e.value.code == 2
 
 
+def test_png_header_cannot_force_huge_allocations():
+    """a ~70-byte PNG announcing 16384 x 16384 x RGBA16 must fail on its (short) data without first reserving
+    the 2 GiB its header asks for; surplus data behind a complete image is ignored, as libpng and the `png` crate do."""
+    import resource
+    ihdr = struct.pack(">IIBBBBB", 16384, 16384, 16, 6, 0, 0, 0)
+    bomb = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(bytes(64))) + _chunk(b"IEND", b"")
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(images.ImageDecodeError, match="too short"):
+        images.decode_image(bomb)
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 64 * 1024        # KiB
+    rng = np.random.default_rng(3)
+    px = rng.integers(0, 256, size=(3, 5, 3), dtype=np.int64)
+    rows = b"".join(b"\x00" + bytes(px[y].reshape(-1).tolist()) for y in range(3))
+    surplus = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", 5, 3, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", zlib.compress(rows + bytes(40))) + _chunk(b"IEND", b"")
+    img = images.decode_image(surplus)
+    assert np.array_equal(img.rgba[..., :3], px.astype(np.uint8))
+
+
 def _jpeg(arr, mode, **kw):
     from PIL import Image
     buf = io.BytesIO()

@@ -61,7 +61,7 @@ def _free_port():
     return p
 
 
-def _split_worker(rank, world, port, out_dir):
+def _split_worker(rank, world, port, out_dir, width=200, height=150):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -72,7 +72,7 @@ def _split_worker(rank, world, port, out_dir):
     from renderer_rs_amd import multigpu
     import oracle_binding as ob
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    scene = m.scenes.random_triangles(400, 200, 150, seed=21, rmin=3, rmax=30)
+    scene = m.scenes.random_triangles(400, width, height, seed=21, rmin=3, rmax=30)
     r0, r1 = multigpu.band_rows(scene.height, rank, world)
     per = multigpu.rows_per_rank(scene.height, world)
     frame = torch.zeros((multigpu.padded_rows(scene.height, world), scene.width, 4), dtype=torch.uint8)
@@ -82,6 +82,11 @@ def _split_worker(rank, world, port, out_dir):
     multigpu.all_gather_bands(frame, rank, world)
     full = ob.render(scene)["bgra8"]
     ok = bool((frame[:scene.height].numpy() == full).all())
+    # the direct pattern of mirhi_comm_all_gather_bands (MIRHI_GATHER_DIRECT): unpadded frame, bands of unequal size
+    direct = torch.zeros((scene.height, scene.width, 4), dtype=torch.uint8)
+    direct[r0:r1] = torch.from_numpy(band[r0:r1])
+    multigpu.exchange_bands_direct(direct, scene.height, rank, world)
+    ok = ok and bool((direct.numpy() == full).all())
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()
@@ -92,3 +97,14 @@ def test_tile_row_split_all_gather_world2(tmp_path):
     port = _free_port()
     mp.spawn(_split_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "rank0.txt").read() == "ok" and open(tmp_path / "rank1.txt").read() == "ok"
+
+
+def test_tile_row_split_world4_uneven_last_band(tmp_path):
+    """1080 rows = 34 tile rows over 4 ranks: bands of 9, 9, 9 and 7 tile rows (288, 288, 288, 216 pixel rows) -- the padded
+    in-place all-gather and the direct exchange of unequal bands both reassemble the oracle's full frame on every rank."""
+    import torch.multiprocessing as mp
+    from renderer_rs_amd import multigpu
+    assert [multigpu.band_rows(1080, r, 4) for r in range(4)] == [(0, 288), (288, 576), (576, 864), (864, 1080)]
+    port = _free_port()
+    mp.spawn(_split_worker, args=(4, port, str(tmp_path), 96, 1080), nprocs=4, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(4)] == ["ok"] * 4
