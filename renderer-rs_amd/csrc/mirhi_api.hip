@@ -255,7 +255,10 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
     d->lanes.push_back(d->stream);
     {
         const hipError_t fe = hipMalloc((void**)&d->frag_stats, 2 * sizeof(unsigned long long));
-        if (fe != hipSuccess || hipMemset(d->frag_stats, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        // (nothing here goes through the NULL stream: it would claim one of the process's few hardware queues -- ROCclr keeps
+        // GPU_MAX_HW_QUEUES = 4 and lets further streams share them -- and two queue lanes that share a hardware queue run their
+        // frames one after the other: C2 12.7 us per frame instead of 8.0, tools/saturation_probe.py)
+        if (fe != hipSuccess || hipMemsetAsync(d->frag_stats, 0, 2 * sizeof(unsigned long long), d->stream) != hipSuccess) {
             if (d->owns_stream) (void)hipStreamDestroy(d->stream);
             delete d; (void)hipGetLastError();
             return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc for the device statistics block");
@@ -267,7 +270,8 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
             const double c = (double)i / 255.0;
             lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
         }
-        const hipError_t le = upload_srgb_lut(lut);
+        hipError_t le = upload_srgb_lut(lut, d->stream);
+        if (le == hipSuccess) le = hipStreamSynchronize(d->stream);
         if (le != hipSuccess) { if (d->owns_stream) (void)hipStreamDestroy(d->stream); delete d; return hip_fail(le, "sRGB table upload"); }
     }
     *out = d;
@@ -1300,7 +1304,10 @@ static mirhi_result stats_params_for(mirhi_cmd* c) {
             P.prim_out = w.stats_prim;
             copies.push_back(P);
         }
-    if (!copies.empty()) HIP_TRY(hipMemcpy(w.stats_params, copies.data(), copies.size() * sizeof(PassParams), hipMemcpyHostToDevice));
+    if (!copies.empty()) {
+        HIP_TRY(hipMemcpyAsync(w.stats_params, copies.data(), copies.size() * sizeof(PassParams), hipMemcpyHostToDevice, c->dev->stream));
+        HIP_TRY(hipStreamSynchronize(c->dev->stream));
+    }
     w.stats_params_valid = true;
     return MIRHI_OK;
 }
@@ -1549,7 +1556,8 @@ extern "C" mirhi_result mirhi_device_fragment_stats(mirhi_device* dev, uint64_t*
     NULL_CHECK(dev, "device");
     { mirhi_result r0 = sync_all_lanes(dev); if (r0 != MIRHI_OK) return r0; }
     unsigned long long v[2] = {0, 0};
-    HIP_TRY(hipMemcpy(v, dev->frag_stats, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(v, dev->frag_stats, sizeof v, hipMemcpyDeviceToHost, dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
     if (shaded_pixels) *shaded_pixels = v[0];
     if (covered_fragments) *covered_fragments = v[1];
     if (scopes) { std::lock_guard<std::mutex> lock(dev->mu); *scopes = dev->frag_scopes; }
@@ -1566,7 +1574,8 @@ extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
     if (dev->base_stop) { dev->free_events.push_back(dev->base_stop); dev->base_stop = nullptr; }
     dev->base_end_ms = 0.0;
     dev->frag_scopes = 0;
-    HIP_TRY(hipMemset(dev->frag_stats, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(dev->frag_stats, 0, 2 * sizeof(unsigned long long), dev->stream));
+    HIP_TRY(hipStreamSynchronize(dev->stream));
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out) {

@@ -37,8 +37,8 @@ namespace mirhi {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
-hipError_t upload_srgb_lut(const float* lut) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_srgb_lut), lut, 256 * sizeof(float), 0, hipMemcpyHostToDevice);
+hipError_t upload_srgb_lut(const float* lut, hipStream_t stream) {
+    return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_srgb_lut), lut, 256 * sizeof(float), 0, hipMemcpyHostToDevice, stream);
 }
 
 // A plain launch, or -- when the caller wants the dispatch timed -- one with an event pair attached to the dispatch itself.

@@ -22,5 +22,5 @@ hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_para
 // a primitive to stats[0]
 hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream);
 // sRGB byte -> linear table of the current device (R8G8B8A8_SRGB textures); 256 floats
-hipError_t upload_srgb_lut(const float* lut);
+hipError_t upload_srgb_lut(const float* lut, hipStream_t stream);   // asynchronous: the caller synchronises `stream`
 }  // namespace mirhi
