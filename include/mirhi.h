@@ -271,7 +271,9 @@ typedef struct {
     uint64_t triangles_submitted;   /* input triangles over those scopes */
     uint64_t workspace_bytes;       /* HBM held for bins / records */
     uint32_t last_big_list;         /* triangles that took the large/overflow list in the last finished scope */
-    uint32_t last_status;           /* device status word of the last finished scope (0 = ok) */
+    uint32_t last_status;           /* device status word of the last finished scope (0 = ok; bit 2: the bin pool ran out and is grown) */
+    uint32_t last_bin_pages;        /* 2 KB bin pages the last finished scope took from the pool (beyond each tile's fixed first page) */
+    uint32_t reserved;
 } mirhi_device_stats;
 mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out);
 

@@ -152,8 +152,11 @@ struct RecordedPass {
 
 struct Workspace {
     DrawDesc* draws = nullptr; size_t draws_cap = 0;
-    TileRec* bin_recs = nullptr; size_t bin_recs_bytes = 0;
-    uint32_t* counters = nullptr; size_t counters_words = 0;   // [tiles] bin counts, then big_count, then status
+    BinRec* bin_pool = nullptr; size_t bin_pool_bytes = 0;     // pages of BIN_PAGE_RECS records: fixed first pages, then the dynamic ones
+    uint32_t* bin_table = nullptr; size_t bin_table_bytes = 0; // [tiles][BIN_TABLE_ROW] page table, PAGE_EMPTY when idle
+    uint32_t pool_scale = 1;                                   // doubled whenever a scope exhausted the pool (applied at the next submit)
+    bool grow_pool = false;
+    uint32_t* counters = nullptr; size_t counters_words = 0;   // [8 * tiles] bin counts, two big-list counters, the pool counter
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
     float* carry_depth = nullptr; size_t carry_depth_bytes = 0;   // depth hand-over between the segments of a scope without a depth attachment
@@ -170,7 +173,7 @@ struct Workspace {
     // of the scopes' parameters that write it, so that the product kernels and parameters stay untouched
     uint32_t* stats_prim = nullptr; size_t stats_prim_bytes = 0;
     PassParams* stats_params = nullptr; size_t stats_params_bytes = 0; bool stats_params_valid = false;
-    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_recs_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes + flat_color_bytes; }
+    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_pool_bytes + bin_table_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes + flat_color_bytes; }
 };
 
 enum CmdState { CMD_INITIAL = 0, CMD_RECORDING = 1, CMD_EXECUTABLE = 2 };
@@ -649,7 +652,8 @@ extern "C" void mirhi_rendering_info_default(mirhi_rendering_info* i) {
 static void free_workspace(mirhi_cmd* c) {
     Workspace& w = c->ws;
     if (w.draws) (void)hipFree(w.draws);
-    if (w.bin_recs) (void)hipFree(w.bin_recs);
+    if (w.bin_pool) (void)hipFree(w.bin_pool);
+    if (w.bin_table) (void)hipFree(w.bin_table);
     if (w.counters) (void)hipFree(w.counters);
     if (w.big_recs) (void)hipFree(w.big_recs);
     if (w.vs_jobs) (void)hipFree(w.vs_jobs);
@@ -1044,17 +1048,26 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles) {
     return m;
 }
 
+// Sizes the workspace of a recorded command buffer and builds its launch plan.  Runs at end() and again in front of a submit
+// when an earlier submission exhausted the bin pool (Workspace::grow_pool).
+static mirhi_result build_plan(mirhi_cmd* cmd);
 extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     REQUIRE_RECORDING(cmd);
     if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
+    mirhi_result r = build_plan(cmd);
+    if (r != MIRHI_OK) return r;
+    cmd->state = CMD_EXECUTABLE;
+    return MIRHI_OK;
+}
+static mirhi_result build_plan(mirhi_cmd* cmd) {
     mirhi_device* dev = cmd->dev;
     HIP_TRY(hipSetDevice(dev->ordinal));
     // the workspace may still be in use by an earlier submission of this command buffer
     if (cmd->lane >= dev->lanes.size()) cmd->lane = 0;
     hipStream_t stream = dev->lanes[cmd->lane];
     HIP_TRY(hipStreamSynchronize(stream));
-    size_t total_draws = 0, max_tiles = 0, max_bin_bytes = 0, max_big = 0;
-    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, big_cap; };
+    size_t total_draws = 0, max_tiles = 0, max_pages = 0, max_big = 0;
+    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages; bool xcd_bins; };
     std::vector<Geo> geo;
     for (auto& pass : cmd->passes) {
         const mirhi_image* ci = pass.info.color_image;
@@ -1062,26 +1075,31 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         g.tiles_x = (ci->width + TILE - 1) / TILE; g.tiles_y = (ci->height + TILE - 1) / TILE;
         band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-        size_t cap = tiles ? (8ull * pass.total_tris) / tiles + 64 : 64;
-        {   // A mesh concentrates its triangles in the tiles it covers (the dancer asset: 17k triangles in 232 of 2040 tiles,
-            // 919 in the fullest), so the average says little: give every tile room for 1024 records (or all of them, if
-            // the scope has fewer) before it has to overflow into the big list, which EVERY tile walks.  Costs address
-            // space only (48 B x cap x tiles: 100 MB at 1080p, 400 MB at 4K); measured: dancer raster 134 -> 97 us, C3
-            // 41.6 -> 37.3 us, C2 / C5 unchanged.  MIRHI_BIN_CAP_FLOOR overrides for A/B runs.
-            size_t floor_cap = getenv("MIRHI_BIN_CAP_FLOOR") ? (size_t)atoi(getenv("MIRHI_BIN_CAP_FLOOR")) : 1024;
-            if (floor_cap > pass.total_tris) floor_cap = pass.total_tris;
-            if (cap < floor_cap) cap = floor_cap;
-        }
         const RasterMode mode = raster_mode(pass, tiles);
-        if (mode.teams == 2u && cap < 2048) cap = 2048;       // eight per-XCD sub-bins of at least 256 records
-        cap = (cap + 511) & ~(size_t)511;                     // (a multiple of 8 x 64)
-        if (cap > 4096) cap = 4096;
-        g.bin_cap = (uint32_t)cap;
+        g.xcd_bins = mode.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
+        // A tile's bin holds up to BIN_TABLE_ROW pages (4096 records; eight lists of 512 with per-XCD bins) before it spills into
+        // the big list, which EVERY tile walks -- the limit costs nothing until it is used: pages come out of one pool, sized by
+        // the scope's triangle count, not by tiles x capacity (round 1: 100 MB at 1080p, 400-510 MB at 4K per command buffer).
+        // MIRHI_BIN_CAP (records per list, A/B runs and the spill tests) lowers it.
+        uint32_t cap = (uint32_t)BIN_TABLE_ROW * BIN_PAGE_RECS;
+        if (getenv("MIRHI_BIN_CAP")) cap = std::min<uint32_t>(cap, std::max<uint32_t>(8u * BIN_PAGE_RECS, ((uint32_t)atoi(getenv("MIRHI_BIN_CAP")) + 511u) & ~511u));
+        g.bin_cap = cap; g.sub_cap = g.xcd_bins ? cap / 8u : cap;
+        // Pool: the first page of every single-list bin has a fixed place (page = tile); the dynamic part is sized for the
+        // (triangle, tile) pairs the scope is likely to produce -- 8 per triangle for small scopes (scattered 50-pixel triangles
+        // make 5), towards 1.5 for big meshes (1.2 measured on the 1M-triangle grid) -- plus one partly filled page per list.  A scope
+        // that needs more spills into the big list (correct, slower) and the pool is doubled for the next submit.
+        const size_t tris = pass.total_tris - pass.first_tri;
+        size_t pairs = std::max(std::max(std::min<size_t>(8 * tris, 262144), std::min<size_t>(3 * tris, 786432)), 3 * tris / 2);
+        pairs *= cmd->ws.pool_scale;
+        if (pairs > 16 * tris) pairs = 16 * tris;                        // (a binned triangle spans at most 4 x 4 tiles)
+        g.fixed_pages = g.xcd_bins ? 0u : (uint32_t)tiles;
+        size_t pages = g.fixed_pages + pairs / BIN_PAGE_RECS + tiles * (g.xcd_bins ? 2 : 1) + 64;
+        if (getenv("MIRHI_POOL_PAGES")) pages = g.fixed_pages + (size_t)atoi(getenv("MIRHI_POOL_PAGES"));      // (pool-exhaustion test)
         g.big_cap = pass.total_tris + pass.total_tris / 4 + 1024;
         geo.push_back(g);
         total_draws += pass.draws.size();
         if (tiles > max_tiles) max_tiles = tiles;
-        if (tiles * cap * sizeof(TileRec) > max_bin_bytes) max_bin_bytes = tiles * cap * sizeof(TileRec);
+        if (pages > max_pages) max_pages = pages;
         if (g.big_cap > max_big) max_big = g.big_cap;
     }
     Workspace& w = cmd->ws;
@@ -1089,10 +1107,14 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     size_t draws_bytes = w.draws_cap * sizeof(DrawDesc);
     if ((r = grow(&w.draws, &draws_bytes, (total_draws ? total_draws : 1) * sizeof(DrawDesc))) != MIRHI_OK) return r;
     w.draws_cap = draws_bytes / sizeof(DrawDesc);
-    if ((r = grow(&w.bin_recs, &w.bin_recs_bytes, max_bin_bytes ? max_bin_bytes : sizeof(TileRec))) != MIRHI_OK) return r;
+    if ((r = grow(&w.bin_pool, &w.bin_pool_bytes, (max_pages ? max_pages : 1) * BIN_PAGE_RECS * sizeof(BinRec))) != MIRHI_OK) return r;
+    if ((r = grow(&w.bin_table, &w.bin_table_bytes, (max_tiles ? max_tiles : 1) * BIN_TABLE_ROW * sizeof(uint32_t))) != MIRHI_OK) return r;
+    HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
+    const size_t pool_pages = w.bin_pool_bytes / (BIN_PAGE_RECS * sizeof(BinRec));
+    w.grow_pool = false;
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
     size_t counter_bytes = w.counters_words * 4;
-    const size_t want_words = 8 * max_tiles + 8;          // bin counters (one per tile, or one per tile and XCD), big-list counters
+    const size_t want_words = 8 * max_tiles + 8;          // bin counters (one per tile, or one per tile and XCD), big-list counters, pool counter
     const bool fresh = !(w.counters && counter_bytes >= want_words * 4);
     if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
     w.counters_words = counter_bytes / 4;
@@ -1104,7 +1126,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     }
     w.stats_params_valid = false;
     hand_over_status(cmd);          // an earlier submission's status is not lost to the re-arm below
-    w.status_host[0] = 0; w.status_host[1] = 0;
+    w.status_host[0] = 0; w.status_host[1] = 0; w.status_host[2] = 0;
     w.big_counts = w.counters + 8 * max_tiles;
     w.parity = 0;
 
@@ -1217,7 +1239,9 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         if (pass.carry_in) P.depth_load = 1u;
         if (pass.carry_out) P.depth_store = 1u;
         P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
-        P.bin_recs = w.bin_recs; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
+        P.bin_pool = w.bin_pool; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
+        P.bin_table = w.bin_table; P.pool_next = w.big_counts + 2;
+        P.pool_dyn_base = g.fixed_pages; P.pool_dyn_pages = (uint32_t)(pool_pages - g.fixed_pages);
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
         P.frag_stats = dev->frag_stats;
@@ -1232,9 +1256,8 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0));
             P.tp_max_area = mode.tp_max_area;
             P.raster_teams = mode.teams;
-            const bool xcd_bins = mode.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
-            P.sub_cap = xcd_bins ? g.bin_cap / 8u : g.bin_cap;
-            P.count_stride = xcd_bins ? (uint32_t)max_tiles : 0u;
+            P.sub_cap = g.sub_cap;
+            P.count_stride = g.xcd_bins ? (uint32_t)max_tiles : 0u;
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
         P.vs_jobs = w.vs_jobs + all_jobs.size();
@@ -1278,7 +1301,6 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         HIP_TRY(hipMemcpyAsync(w.params, dev_params.data(), dev_params.size() * sizeof(PassParams), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     dev->stats.workspace_bytes = w.bytes();
-    cmd->state = CMD_EXECUTABLE;
     return MIRHI_OK;
 }
 
@@ -1333,6 +1355,11 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     }
     if (fence && fence->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: fence belongs to another device");
     HIP_TRY(hipSetDevice(dev->ordinal));
+    for (uint32_t i = 0; i < cmd_count; i++)
+        if (cmds[i]->ws.grow_pool && !getenv("MIRHI_POOL_PAGES")) {       // an earlier submission ran out of bin pages: a bigger pool, the same plan
+            const mirhi_result rp = build_plan(cmds[i]);
+            if (rp != MIRHI_OK) return rp;
+        }
     std::lock_guard<std::mutex> lock(dev->mu);
     for (uint32_t i = 0; i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
@@ -1417,6 +1444,14 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
     if (c->ws.status_host) {
         dev->stats.last_status = c->ws.status_host[0];
         dev->stats.last_big_list = c->ws.status_host[1];
+        dev->stats.last_bin_pages = c->ws.status_host[2];
+        if ((c->ws.status_host[0] & STATUS_POOL_EXHAUSTED) && !c->ws.grow_pool) {
+            // not an error: the records went to the big list and the frame is complete; the pool is doubled in front of the next submit
+            c->ws.grow_pool = true;
+            if (c->ws.pool_scale < 64u) c->ws.pool_scale *= 2u;
+        }
+        if (c->ws.status_host[0] & STATUS_PAGE_TIMEOUT)
+            r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer bin page was never published; frame is incomplete");
         if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
             r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: MODEL_PBR alpha cutoff together with a base colour texture (per-fragment discard); that draw was skipped");
         if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)

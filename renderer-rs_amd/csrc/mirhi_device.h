@@ -2,11 +2,13 @@
 //
 // Data layout in HBM (see DESIGN.md "Data layout"):
 //   DrawDesc[]   one per recorded draw of a rendering scope (pointers into caller buffers + state)
-//   TileRec[]    per-tile bins: tiles * bin_cap records of 48 B, written by the geometry kernel,
-//                consumed by exactly one raster workgroup
-//   BigRec[]     screen-space triangles too large for the bins (or spilled from a full bin);
-//                every raster workgroup scans this list
-//   counters     bin_count[tiles], big_count, status word
+//   BinRec[]     the bin pool: pages of 64 tile-relative triangle records of 32 B.  A tile's bin is a list of pages -- the
+//                first one at a fixed place (page = tile), further ones taken from the pool by the geometry kernel and
+//                entered in the tile's row of the page table -- written by the geometry kernel, consumed by exactly one
+//                raster workgroup
+//   BigRec[]     screen-space triangles (48 B, absolute coordinates) too large for the bins, clipped, cut by a scissor, or
+//                spilled from a full bin / an exhausted pool; every raster workgroup scans this list
+//   counters     bin_count[tiles], pool_next, big_count, status words
 #pragma once
 #include <stdint.h>
 
@@ -21,10 +23,17 @@ constexpr int TP_MIN_LANES = 32;      // small records a wave must hold before i
 constexpr int GEOM_THREADS = 64;
 constexpr int MAX_BIN_SPAN = 4;       // triangles spanning more than 4x4 tiles go to the big list
 constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay inside +-2^22 sub-pixels
+constexpr int BIN_PAGE_RECS = 64;     // records per bin page (2 KB)
+constexpr int BIN_PAGE_LOG2 = 6;
+constexpr int BIN_TABLE_ROW = 64;     // page-table entries per tile: 64 pages of one list, or 8 pages for each of 8 per-XCD lists
+constexpr uint32_t PAGE_EMPTY = 0xFFFFFFFFu;   // table entry not (yet) published
+constexpr uint32_t PAGE_NONE = 0xFFFFFFFEu;    // the pool was exhausted when this page was asked for: its records go to the big list
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
 constexpr uint32_t MAX_PRIM_ID = 0xFFFFFFFDu;
 
-enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u };
+enum : uint32_t { STATUS_BIG_OVERFLOW = 1u, STATUS_ALPHA_TEST_TEXTURED = 2u,
+                  STATUS_POOL_EXHAUSTED = 4u,      // not an error: records went to the big list instead; the host grows the pool
+                  STATUS_PAGE_TIMEOUT = 8u };      // a page was never published (cannot happen by construction; bounded wait)
 constexpr uint32_t ORDERED_MARKER = 0xFFFFFFFFu;   // bbox-y word of an ordered slot whose triangle was clipped: pieces live in the big list
 constexpr int ORDERED_THREADS = 256;
 
@@ -85,8 +94,16 @@ static_assert(sizeof(VsJob) == 48, "VsJob is 48 bytes");
 //                              bx = minx | maxx << 16 | boxed << 31, by = miny | maxy << 16 (inclusive pixel box)
 struct TriRec { uint32_t w[12]; };
 static_assert(sizeof(TriRec) == 48, "TriRec is 48 bytes");
-typedef TriRec TileRec;   // bins hold TriRec copies
-typedef TriRec BigRec;    // so does the big list
+typedef TriRec BigRec;    // the big list holds TriRecs
+
+// Bin record, 8 dwords = two 16-byte words: the same triangle relative to the tile whose bin it sits in.  Only triangles whose
+// pixel box spans at most 4 x 4 tiles and whose vertices lie within 65535 sub-pixels of each other are binned, so every
+// coordinate is a 16-bit number; the pixel box is recomputed from the vertices (a box cut by a scissor goes to the big list).
+//   w0 = { ox | oy << 16,      smallest vertex x / y minus the tile origin, 1/256 px, signed 16 bit
+//          x0 | y0 << 16, x1 | y1 << 16, x2 | y2 << 16 }   vertices minus (smallest x, smallest y), unsigned 16 bit
+//   w1 = { z0, zx, zy, idk }   as in TriRec
+struct BinRec { uint32_t w[8]; };
+static_assert(sizeof(BinRec) == 32, "BinRec is 32 bytes");
 
 struct PassParams {
     uint32_t width, height;           // colour target extent
@@ -112,7 +129,10 @@ struct PassParams {
     uint32_t depth_load, depth_store;
     uint32_t* prim_out;               // optional R32_UINT image
     // workspace
-    TileRec*  bin_recs; uint32_t* bin_count; uint32_t bin_cap;
+    BinRec*   bin_pool; uint32_t* bin_count; uint32_t bin_cap;     // bin_cap: records a tile's bin can hold (all of its lists)
+    uint32_t* bin_table;              // [tiles][BIN_TABLE_ROW] pool page of the list's p-th page (PAGE_EMPTY until published)
+    uint32_t* pool_next;              // dynamic pages handed out so far in this scope (re-armed by the raster kernel)
+    uint32_t  pool_dyn_base, pool_dyn_pages;   // dynamic pages are pool pages [pool_dyn_base, pool_dyn_base + pool_dyn_pages)
     BigRec*   big_recs; uint32_t* big_count; uint32_t big_cap;
     uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
     uint32_t* prim_draw;              // per primitive of the scope (index prim - first_prim): its draw, written by the geometry kernel when
@@ -123,16 +143,18 @@ struct PassParams {
                                       // triangle-parallel (LDS ds_min) instead of pixel-parallel
     uint32_t xcd_swizzle;             // run length G of consecutive tiles placed on one XCD (1 = plain order)
     uint32_t raster_teams;            // 2: the mesh variant with two teams of four waves per tile (host-side choice, see raster_kernel)
-    // Per-XCD bins (only together with raster_teams == 2): a tile's bin is eight sub-bins of sub_cap records, one per XCD,
-    // each with its own counter (bin_count[xcd * count_stride + tile]), so that a hot tile's counter line stays in one
-    // XCD's L2 -- see reserve_bin_slots.  Off: count_stride = 0, sub_cap = bin_cap.
+    // Per-XCD bins (only together with raster_teams == 2): a tile's bin is eight lists of sub_cap records, one per XCD,
+    // each with its own counter (bin_count[xcd * count_stride + tile]) and its own eight entries of the tile's page-table row,
+    // so that a hot tile's counter line stays in one XCD's L2 -- see reserve_bin_slots.  Off: count_stride = 0, sub_cap =
+    // bin_cap, and the first page of every tile's single list has a fixed place in the pool (page = tile): the common bin
+    // needs neither an allocation nor a table entry.
     uint32_t sub_cap, count_stride;
     // ordered segments (blending; any depth state whose result depends on the order of all fragments): the geometry kernel
     // writes triangle t of the segment to ordered_recs[t] instead of binning it, the ordered kernel walks that array
     TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;
     uint32_t ord_depth_test, ord_depth_write, ord_depth_op;
     uint32_t blend[8];                // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
-    uint32_t* status;                 // pinned host memory: [0] error bits (atomicOr), [1] big-list length of the last scope
+    uint32_t* status;                 // pinned host memory: [0] status bits (atomicOr), [1] big-list length, [2] dynamic pages of the last scope
     unsigned long long* frag_stats;   // device counters of the statistics pass (never touched by geometry / raster kernels): [0] pixels that
                                       // ran a fragment program (winners of the depth resolve), [1] fragments covered before the depth test
 };
@@ -141,7 +163,7 @@ struct PassParams {
 // first dependent loads (draw table, bin counter -> bin records) hang off the kernarg load, not off a second memory hop.
 struct GeometryHead { const DrawDesc* draws; uint32_t num_draws; };
 struct RasterHead {
-    uint32_t* bin_count; const TileRec* bin_recs; uint32_t* big_count;
+    uint32_t* bin_count; const BinRec* bin_pool; uint32_t* big_count;
     uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;
     uint32_t sub_cap, count_stride;   // per-XCD bins (PassParams); read by the two-team variant only
 };

@@ -27,13 +27,16 @@ __device__ __forceinline__ f4 vs_position(DrawRef D, uint32_t vidx, f3* world) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// screen-space triangle record (TriRec, 48 B) and its tile-relative form (TileRec, 64 B, LDS only)
+// screen-space triangle record (TriRec, 48 B; big list), the bin record (BinRec, 32 B, relative to its tile) and the raster
+// kernel's working form (64 B, LDS only)
 // ------------------------------------------------------------------------------------------------
 struct ScreenTri {
     int32_t X[3], Y[3];          // 1/256 px, orientation normalised (interior has E > 0)
     float z0, zx, zy;
     int32_t minx, maxx, miny, maxy;   // inclusive pixel bbox (scissor-clamped)
     uint32_t idk, boxed;
+    int32_t vminx, vminy;             // smallest vertex coordinates, 1/256 px
+    uint32_t compact;                 // the vertices lie within 65535 sub-pixels of (vminx, vminy) and no scissor cuts the box
 };
 
 __device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
@@ -93,6 +96,8 @@ __device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 
     if (py1 < band0 || py0 > band1) return false;
     t.minx = px0; t.maxx = px1; t.miny = py0; t.maxy = py1;
     t.boxed = cut ? 1u : 0u;
+    t.vminx = xmin; t.vminy = ymin;
+    t.compact = (!cut && xmax - xmin <= 65535 && ymax - ymin <= 65535) ? 1u : 0u;
     t.idk = P.idflip ? (MAX_PRIM_ID - prim) : prim;
     return true;
 }
@@ -281,22 +286,71 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
     if (gsize) raw = atomicAdd(&P.bin_count[xcd * P.count_stride + tile], gsize);
     return raw;
 }
+
+// ------------------------------------------------------------------------------------------------
+// bin pages.  A list's slot s lives in its page s / 64 at offset s % 64.  Without per-XCD lists the first page of a tile has a
+// fixed place (pool page = tile): the usual bin costs no allocation.  Any other page is taken from the pool by the ONE lane
+// whose slot is the page's first (s % 64 == 0) and published in the tile's row of the page table; the lanes that drew the
+// other slots of that page (this wave or another) read the entry until it is there.  Waiting is safe: the publishing lane has
+// executed its reservation (its slot is smaller), and a wave publishes every page of a batch of reservations before it waits
+// for anyone (bin_triangle_pairs), so no wave ever waits for a wave that waits for it.  The wait is bounded all the same.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bin_table_entry(ParamsRef P, uint32_t tile, uint32_t xcd, uint32_t slot) {
+    return tile * (uint32_t)BIN_TABLE_ROW + (P.count_stride ? xcd * 8u : 0u) + (slot >> BIN_PAGE_LOG2);
+}
+__device__ __forceinline__ uint32_t bin_page_alloc(ParamsRef P, uint32_t entry) {
+    const uint32_t id = atomicAdd(P.pool_next, 1u);
+    uint32_t page = P.pool_dyn_base + id;
+    if (id >= P.pool_dyn_pages) {      // pool exhausted: the page's records take the big list; the host grows the pool for the next submit
+        page = PAGE_NONE;
+        __hip_atomic_fetch_or(P.status, STATUS_POOL_EXHAUSTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(&P.bin_table[entry], page, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return page;
+}
+__device__ __forceinline__ uint32_t bin_page_wait(ParamsRef P, uint32_t entry) {
+    for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        const uint32_t page = __hip_atomic_load(&P.bin_table[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (page != PAGE_EMPTY) return page;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_fetch_or(P.status, STATUS_PAGE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return PAGE_NONE;
+}
+// the triangle relative to tile (tx, ty): c0 = { vminx, vminy, x0|y0<<16, x1|y1<<16 }, c1 = { x2|y2<<16, z0, zx, zy }
+__device__ __forceinline__ void store_bin_rec(ParamsRef P, uint32_t page, uint32_t slot, uint4 c0, uint4 c1, uint32_t idk, int32_t tx, int32_t ty) {
+    const int32_t ox = (int32_t)c0.x - tx * (TILE * 256), oy = (int32_t)c0.y - ty * (TILE * 256);
+    uint4* dst = reinterpret_cast<uint4*>(P.bin_pool) + ((size_t)page * BIN_PAGE_RECS + (slot & (BIN_PAGE_RECS - 1u))) * 2u;
+    dst[0] = make_uint4(((uint32_t)ox & 0xFFFFu) | ((uint32_t)oy << 16), c0.z, c0.w, c1.x);
+    dst[1] = make_uint4(c1.y, c1.z, c1.w, idk);
+}
+
 template <uint32_t BATCH>
 __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
                                                    uint32_t* lds_meta, uint16_t* lds_owner) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t xcd = P.count_stride ? xcd_of_wave() : 0u;        // wave-uniform
+    const bool fixed_first = P.count_stride == 0u;                     // the first page of a list has a fixed place
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
     bool spill = false;
     if (valid) {
         tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
         ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
         nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
-        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN;
+        // a bin record is 16-bit relative to its tile: the triangle's smallest coordinates must be within reach of every tile of
+        // its span (they always are unless the triangle hangs far out of the target or the band)
+        const int32_t tw = TILE * 256;
+        const bool fits = t.compact && t.vminx - tx0 * tw <= 32767 && t.vminx - (tx0 + ntx - 1) * tw >= -32768 &&
+                          t.vminy - ty0 * tw <= 32767 && t.vminy - (ty0 + nty - 1) * tw >= -32768;
+        spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN || !fits;
     }
     const bool binned = valid && !spill;
     const uint32_t nb = binned ? (uint32_t)(ntx * nty) : 0u;
+    // the triangle relative to its smallest coordinates (store_bin_rec); built where it is used, not held across the branches
+#define MIRHI_COMPACT_C0 make_uint4((uint32_t)t.vminx, (uint32_t)t.vminy, (uint32_t)(t.X[0] - t.vminx) | ((uint32_t)(t.Y[0] - t.vminy) << 16), \
+                                    (uint32_t)(t.X[1] - t.vminx) | ((uint32_t)(t.Y[1] - t.vminy) << 16))
+#define MIRHI_COMPACT_C1 make_uint4((uint32_t)(t.X[2] - t.vminx) | ((uint32_t)(t.Y[2] - t.vminy) << 16), __float_as_uint(t.z0), __float_as_uint(t.zx), __float_as_uint(t.zy))
     if (__ballot(nb > 1u) == 0ull) {
         // Fine meshes: no triangle of the wave overlaps more than one tile.  A lane is its own pair -- no enumeration
         // through LDS, the record goes out of the registers it was built in.
@@ -306,8 +360,16 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who, xcd);
         const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
         if (act) {
-            if (slot < P.sub_cap) store_tri(reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + xcd * P.sub_cap + slot) * 3u, t);
-            else spill = true;       // bin full: the triangle goes to the big list
+            uint32_t page = PAGE_NONE;
+            if (slot < P.sub_cap) {
+                if (fixed_first && slot < (uint32_t)BIN_PAGE_RECS) page = tile;
+                else {
+                    const uint32_t entry = bin_table_entry(P, tile, xcd, slot);
+                    page = (slot & (BIN_PAGE_RECS - 1u)) == 0u ? bin_page_alloc(P, entry) : bin_page_wait(P, entry);
+                }
+            }
+            if (page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, ty0);
+            else spill = true;       // list full or pool exhausted: the triangle goes to the big list
         }
         if (valid && spill) emit_big(P, t);
         return;
@@ -321,10 +383,9 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         total += (uint32_t)__popcll(m) << bit;
     }
     if (binned) {
-        lds_tri[lane][0] = make_uint4((uint32_t)t.X[0], (uint32_t)t.Y[0], (uint32_t)t.X[1], (uint32_t)t.Y[1]);
-        lds_tri[lane][1] = make_uint4((uint32_t)t.X[2], (uint32_t)t.Y[2], __float_as_uint(t.z0), __float_as_uint(t.zx));
-        lds_tri[lane][2] = make_uint4(__float_as_uint(t.zy), t.idk, (uint32_t)t.minx | ((uint32_t)t.maxx << 16) | (t.boxed << 31),
-                                      (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
+        lds_tri[lane][0] = MIRHI_COMPACT_C0;
+        lds_tri[lane][1] = MIRHI_COMPACT_C1;
+        lds_tri[lane][2] = make_uint4(t.idk, (uint32_t)tx0 | ((uint32_t)ty0 << 16), 0u, 0u);
         lds_meta[lane] = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
         uint32_t pos = ex;
 #pragma unroll
@@ -333,17 +394,19 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         }
     }
     __syncthreads();            // one wave per workgroup: orders the LDS writes above before the reads below
-    // The returning atomics of up to BATCH rounds (one instruction per 64 pairs, reserve_bin_slots) are issued before the
-    // first result is consumed; a wave with more pairs takes another batch.  BATCH = 8 for the small-scope variant of the kernel: with four, C2 (about
-    // 320 pairs a wave) paid a second serial round trip, 7.4 -> 8.2 us; 4 for the occupancy-oriented one (8 spills at 72 VGPRs).
-    // (All sixteen possible rounds in one batch held 32 result registers live and kept the kernel at 86 VGPRs.)
+    // Three phases per batch of up to BATCH rounds (64 pairs each):
+    //   1. the returning atomics of all rounds (one instruction per 64 pairs, reserve_bin_slots) are issued before the first
+    //      result is consumed.  BATCH = 8 for the small-scope variant of the kernel: with four, C2 (about 320 pairs a wave) paid
+    //      a second serial round trip, 7.4 -> 8.2 us; 4 for the occupancy-oriented one (8 spills at 72 VGPRs).
+    //   2. lanes whose slot opens a page take it from the pool and publish it -- for ALL rounds, before
+    //   3. the records are stored; a lane whose page another lane opens waits for the table entry here (see "bin pages").
 #pragma unroll 1
     for (uint32_t it0 = 0; it0 * GEOM_THREADS < total; it0 += BATCH) {
-        uint32_t raw[BATCH];       // atomic result (held by the reserving lane)
-        uint32_t who[BATCH];       // reserving lane | rank within its group << 8
+        uint32_t slot[BATCH];      // phase 1: atomic result (held by the reserving lane); from phase 2 on: the lane's own slot
+        uint32_t aux[BATCH];       // phase 1: reserving lane | rank within its group << 8; from phase 2 on: the pool page, if known
 #pragma unroll
         for (uint32_t k = 0; k < BATCH; k++) {
-            raw[k] = 0; who[k] = lane;
+            slot[k] = 0; aux[k] = lane;
             const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
             if ((it0 + k) * GEOM_THREADS >= total) continue;
             const bool act = p < total;
@@ -352,21 +415,40 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                 const uint32_t o = lds_owner[p], kk = o >> 8;
                 tile = (lds_meta[o & 0xFFu] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
             }
-            raw[k] = reserve_bin_slots(P, act, tile, lane, lt, who[k], xcd);
+            slot[k] = reserve_bin_slots(P, act, tile, lane, lt, aux[k], xcd);
         }
 #pragma unroll
         for (uint32_t k = 0; k < BATCH; k++) {
             if ((it0 + k) * GEOM_THREADS >= total) continue;
             const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
-            const uint32_t slot = (uint32_t)__shfl((int)raw[k], (int)(who[k] & 0xFFu)) + (who[k] >> 8);
+            const uint32_t s = (uint32_t)__shfl((int)slot[k], (int)(aux[k] & 0xFFu)) + (aux[k] >> 8);
+            slot[k] = s; aux[k] = PAGE_EMPTY;
+            if (p < total && s < P.sub_cap && (s & (BIN_PAGE_RECS - 1u)) == 0u && !(fixed_first && s == 0u)) {
+                const uint32_t o = lds_owner[p], kk = o >> 8;
+                const uint32_t tile = (lds_meta[o & 0xFFu] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
+                aux[k] = bin_page_alloc(P, bin_table_entry(P, tile, xcd, s));
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < BATCH; k++) {
+            if ((it0 + k) * GEOM_THREADS >= total) continue;
+            const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
             if (p < total) {
                 const uint32_t o = lds_owner[p], ol = o & 0xFFu, kk = o >> 8;
                 const uint32_t tile = (lds_meta[ol] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
-                if (slot < P.sub_cap) {
-                    uint4* dst = reinterpret_cast<uint4*>(P.bin_recs) + ((size_t)tile * P.bin_cap + xcd * P.sub_cap + slot) * 3u;
-                    dst[0] = lds_tri[ol][0]; dst[1] = lds_tri[ol][1]; dst[2] = lds_tri[ol][2];
+                const uint32_t s = slot[k];
+                uint32_t page = PAGE_NONE;
+                if (s < P.sub_cap) {
+                    if (fixed_first && s < (uint32_t)BIN_PAGE_RECS) page = tile;
+                    else if (aux[k] != PAGE_EMPTY) page = aux[k];
+                    else page = bin_page_wait(P, bin_table_entry(P, tile, xcd, s));
+                }
+                if (page != PAGE_NONE) {
+                    const uint4 m2 = lds_tri[ol][2];
+                    store_bin_rec(P, page, s, lds_tri[ol][0], lds_tri[ol][1], m2.x, (int32_t)(m2.y & 0xFFFFu) + (int32_t)(kk % MAX_BIN_SPAN),
+                                  (int32_t)(m2.y >> 16) + (int32_t)(kk / MAX_BIN_SPAN));
                 } else {
-                    atomicOr(&lds_meta[ol], 0x80000000u);   // bin full: the owner sends the triangle to the big list, once
+                    atomicOr(&lds_meta[ol], 0x80000000u);   // list full / pool exhausted: the owner sends the triangle to the big list, once
                 }
             }
         }
@@ -374,6 +456,8 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
     __syncthreads();
     if (binned && (lds_meta[lane] >> 31)) spill = true;    // (idempotent resolve: being in some bins as well is harmless)
     if (valid && spill) emit_big(P, t);
+#undef MIRHI_COMPACT_C0
+#undef MIRHI_COMPACT_C1
 }
 
 // One wave per workgroup; draws are padded to whole waves so the draw (and with it every uniform, pointer

@@ -31,33 +31,39 @@ __device__ __forceinline__ int64_t mul24x24(int32_t a, int32_t b) {
     return (int64_t)(((uint64_t)(uint32_t)hi << 32) | lo);
 }
 
-// TriRec (screen space) -> TileRec for tile (tx, ty); false if no 8x8 block of the tile can be touched.
+// A triangle in TILE-RELATIVE coordinates (1/256 px from the tile's origin) -> the tile record the pixel loops work on;
+// false if no 8x8 block of the tile can be touched.
 //   w0 = { Q0, Q1, Q2, A0 }   Q_i = floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
 //   w1 = { A1, A2, B0, B1 }   A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23, fits v_mad_i32_i24)
 //   w2 = { B2, dxt, dyt, z0 } (tile origin pixel centre) - (snapped vertex 0), in pixels (exact), vertex-0 depth
 //   w3 = { zx, zy, idk, mask } mask bits 0..15 = 8x8 blocks the triangle may touch, bit 31 = pixel box applies
-__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2,
-                                              int32_t tx, int32_t ty) {
-    const int32_t X[3] = {(int32_t)w0.x, (int32_t)w0.z, (int32_t)w1.x}, Y[3] = {(int32_t)w0.y, (int32_t)w0.w, (int32_t)w1.y};
-    const int32_t ox = tx * TILE, oy = ty * TILE;
-    const int32_t Ptx = 256 * ox + 128, Pty = 256 * oy + 128;           // tile origin pixel centre, 1/256 px
+// box: the triangle's inclusive pixel box clamped to the tile, bx0 | bx1 << 8 | by0 << 16 | by1 << 24 (bx0 > bx1 or by0 > by1: it
+// misses the tile); boxed: 0x80000000 if a scissor cut the box (the pixel loops then test it per pixel)
+struct TileTri { int32_t X[3], Y[3]; uint32_t box, z0, zx, zy, idk, boxed; };
+__device__ __forceinline__ uint32_t clamp_box(int32_t bx0, int32_t bx1, int32_t by0, int32_t by1) {
+    // an empty intersection keeps lo > hi after the clamps: lo in [0, 32], hi in [-1, 31]
+    bx0 = bx0 < 0 ? 0 : (bx0 > TILE ? TILE : bx0); by0 = by0 < 0 ? 0 : (by0 > TILE ? TILE : by0);
+    bx1 = bx1 > TILE - 1 ? TILE - 1 : (bx1 < -1 ? -1 : bx1); by1 = by1 > TILE - 1 ? TILE - 1 : (by1 < -1 ? -1 : by1);
+    return (uint32_t)bx0 | (((uint32_t)bx1 & 0xFFu) << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+}
+
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T) {
+    const int32_t Pt = 128;                                            // tile origin pixel centre, 1/256 px
     int32_t A[3], B[3], Q[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int a = i, b = (i + 1) % 3;
-        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
+        const int32_t dx = T.X[b] - T.X[a], dy = T.Y[b] - T.Y[a];
         A[i] = -dy; B[i] = dx;
         const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
-        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22, |Pt| < 2^21)
-        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
+        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22 and |tile origin| < 2^21 in absolute terms)
+        const int64_t e0 = mul24x24(A[i], Pt - T.X[a]) + mul24x24(B[i], Pt - T.Y[a]) + (topleft ? 0 : -1);
         int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
         q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
         Q[i] = (int32_t)q;
     }
-    int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - ox, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - ox;
-    int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - oy, by1 = (int32_t)(w2.w >> 16) - oy;
-    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
-    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
+    const int32_t bx0 = (int32_t)(T.box & 0xFFu), bx1 = (int32_t)(int8_t)((T.box >> 8) & 0xFFu);
+    const int32_t by0 = (int32_t)((T.box >> 16) & 0xFFu), by1 = (int32_t)T.box >> 24;
     // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
     // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
     // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
@@ -86,14 +92,43 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
     const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
     const float inv256 = 1.0f / 256.0f;
-    const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
-    const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
+    const float dxt = 0.5f - (float)T.X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
+    const float dyt = 0.5f - (float)T.Y[0] * inv256;
     out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
     out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
-    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), w1.z);
-    out[3] = make_uint4(w1.w, w2.x, w2.y, mask | (w2.z & 0x80000000u));
-    box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), T.z0);
+    out[3] = make_uint4(T.zx, T.zy, T.idk, mask | T.boxed);
+    box = T.box;
     return mask != 0;
+}
+
+// BinRec (already relative to its tile) -> TileTri; the pixel box is recomputed from the vertices (no scissor cuts a binned triangle)
+__device__ __forceinline__ void tile_tri_from_bin(TileTri& T, const uint4 w0, const uint4 w1) {
+    const int32_t ox = (int32_t)(w0.x << 16) >> 16, oy = (int32_t)w0.x >> 16;
+    const uint32_t x0 = w0.y & 0xFFFFu, x1 = w0.z & 0xFFFFu, x2 = w0.w & 0xFFFFu, y0 = w0.y >> 16, y1 = w0.z >> 16, y2 = w0.w >> 16;
+    T.X[0] = ox + (int32_t)x0; T.X[1] = ox + (int32_t)x1; T.X[2] = ox + (int32_t)x2;
+    T.Y[0] = oy + (int32_t)y0; T.Y[1] = oy + (int32_t)y1; T.Y[2] = oy + (int32_t)y2;
+    const int32_t xmax = ox + (int32_t)max(x0, max(x1, x2)), ymax = oy + (int32_t)max(y0, max(y1, y2));
+    T.box = clamp_box((ox + 127) >> 8, (xmax - 128) >> 8, (oy + 127) >> 8, (ymax - 128) >> 8);     // as setup_triangle, in tile-relative pixels
+    T.z0 = w1.x; T.zx = w1.y; T.zy = w1.z; T.idk = w1.w; T.boxed = 0u;
+}
+// TriRec (absolute coordinates, big list) -> TileTri for tile (tx, ty); false if its pixel box misses the tile
+__device__ __forceinline__ bool tile_tri_from_big(TileTri& T, const uint4 w0, const uint4 w1, const uint4 w2, int32_t tx, int32_t ty) {
+    const int32_t opx = tx * TILE, opy = ty * TILE, ox = opx * 256, oy = opy * 256;
+    const int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - opx, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - opx;
+    const int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - opy, by1 = (int32_t)(w2.w >> 16) - opy;
+    if (bx1 < 0 || bx0 > TILE - 1 || by1 < 0 || by0 > TILE - 1) return false;
+    T.box = clamp_box(bx0, bx1, by0, by1);
+    T.X[0] = (int32_t)w0.x - ox; T.Y[0] = (int32_t)w0.y - oy; T.X[1] = (int32_t)w0.z - ox; T.Y[1] = (int32_t)w0.w - oy;
+    T.X[2] = (int32_t)w1.x - ox; T.Y[2] = (int32_t)w1.y - oy;
+    T.z0 = w1.z; T.zx = w1.w; T.zy = w2.x; T.idk = w2.y; T.boxed = w2.z & 0x80000000u;
+    return true;
+}
+// TriRec words -> tile record of tile (tx, ty) in one step (ordered segments: their records never pass through bins)
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2, int32_t tx, int32_t ty) {
+    TileTri T;
+    if (!tile_tri_from_big(T, w0, w1, w2, tx, ty)) { box = 0u; return false; }
+    return make_tile_rec(out, box, T);
 }
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
@@ -269,15 +304,16 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // TEAMS > 1 (mesh variants): the workgroup is TEAMS sets of four waves; team t stages and rasters chunks t, t + TEAMS, ...
 // of the list into its own staging area and its own register keys (tid = lane index within the team).  Every team runs
 // the same number of passes -- the barriers are workgroup-wide -- a team whose chunk lies beyond the list stages nothing.
-// seg (two-team variant, bin list only): the bin is eight per-XCD sub-bins of sub_cap records; seg[k] = records in the
+// seg (two-team variant, bin list only): the bin is eight per-XCD lists of at most sub_cap records; seg[k] = records in the
 // sub-bins before k, so that flat index i lives in sub-bin #{k >= 1 : i >= seg[k]} at offset i - seg[that].  nullptr: a plain list.
+// bins: `list` is the bin pool and flat index i of the tile's bin lives in pool page pages[...] (LDS copy of the tile's page-table
+// row; the first page of a single-list bin is page `tile` itself); otherwise `list` is a plain TriRec array (the big list).
 template <int KEYED, int TP, int CHUNK, int TEAMS>
-__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, const uint32_t* seg, uint32_t sub_cap, uint4* lds_rec, uint32_t* lds_box,
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, bool bins, uint32_t tile, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
                                             uint32_t lane) {
-    const int32_t tpx0 = (int32_t)(tx * TILE), tpy0 = (int32_t)(ty * TILE);
     // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
     const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
@@ -298,20 +334,28 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
         if (ftid < (uint32_t)CHUNK && i < n_total) {
-            // all three words are requested together: one memory round trip, not two (a bin holds only records whose
-            // box overlaps the tile, so the box test below almost never saves the first two loads)
-            size_t ri = i;
-            if (TEAMS > 1 && seg) {
-                uint32_t k = 0;
+            TileTri T;
+            if (bins) {
+                // flat index -> (list, slot) -> pool page; both words of the record are requested together
+                uint32_t k = 0, j = i;
+                if (TEAMS > 1 && seg) {
 #pragma unroll
-                for (uint32_t j = 1; j < 8u; j++) k += i >= seg[j] ? 1u : 0u;
-                ri = (size_t)k * sub_cap + (i - seg[k]);
+                    for (uint32_t q = 1; q < 8u; q++) k += i >= seg[q] ? 1u : 0u;
+                    j = i - seg[k];
+                }
+                const uint32_t page = (!seg && j < (uint32_t)BIN_PAGE_RECS) ? tile : pages[k * 8u + (j >> BIN_PAGE_LOG2)];
+                hit = page < PAGE_NONE;            // (a page the exhausted pool could not supply: its records are in the big list)
+                if (hit) {
+                    const uint32_t ri = (page * (uint32_t)BIN_PAGE_RECS + (j & (BIN_PAGE_RECS - 1u))) * 2u;      // (pools stay far below 2^32 words)
+                    const uint4 w0 = list[ri], w1 = list[ri + 1u];
+                    tile_tri_from_bin(T, w0, w1);
+                }
+            } else {
+                // all three words are requested together: one memory round trip, not two
+                const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
+                hit = tile_tri_from_big(T, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
             }
-            const uint4 w0 = list[ri * 3u], w1 = list[ri * 3u + 1u], w2 = list[ri * 3u + 2u];
-            const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
-            const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
-            hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
-            if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
+            if (hit) hit = make_tile_rec(rec, box, T);
         }
         bool small = false, boxed = false;
         if (hit) {
@@ -417,6 +461,10 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     }
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
+    // The tile's row of the page table is needed only beyond the first (fixed) page of a single-list bin, or with per-XCD lists.
+    __shared__ uint32_t lds_pages[BIN_TABLE_ROW];
+    const bool need_pages = xcd_bins || count > (uint32_t)BIN_PAGE_RECS;
+    if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) lds_pages[threadIdx.x] = P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x];
     // (Letting the second team leave tiles whose lists fit one staging pass was measured: the scopes that get this variant
     // leave most of the chip idle anyway, and those tiles then lose the split resolve: dancer 43 -> 46 us, 49 -> 57 us textured.)
     constexpr bool solo = TEAMS == 1;
@@ -428,6 +476,8 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     if (tid == 0 && team == 0 && tile == 0) {
         *P.big_count_next = 0;                              // the next scope on this workspace appends to the other counter
         P.status[1] = nbig_raw;
+        P.status[2] = *P.pool_next;                         // dynamic bin pages of this scope; no raster workgroup reads the counter,
+        *P.pool_next = 0;                                   // and the next geometry kernel on this workspace is ordered behind this kernel
     }
 
     if (count == 0u && nbig == 0u) {
@@ -483,11 +533,11 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     STAMP(1);
     STAGE_END(1u);
     // the tile's bin, then the list every tile tests (large / clipped / spilled triangles): one copy of the code
-    const uint4* list = reinterpret_cast<const uint4*>(H.bin_recs) + (size_t)tile * H.bin_cap * 3u;
+    const uint4* list = reinterpret_cast<const uint4*>(H.bin_pool);
     uint32_t n_list = count;
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, (xcd_bins && pass == 0) ? lds_seg : nullptr, H.sub_cap, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, pass == 0, tile, lds_pages, (xcd_bins && pass == 0) ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                            qbit0, tid, lane);
         if (pass == 0) {
             STAMP(2);
@@ -495,6 +545,8 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
                 H.bin_count[tile] = 0;
                 if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[k * H.count_stride + tile] = 0;
             }
+            // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
+            if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
             if (!nbig) break;
             // parameters of this phase are (re)read here, see launder_params
             list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);

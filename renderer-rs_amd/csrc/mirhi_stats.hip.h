@@ -10,14 +10,9 @@
 // Runs between geometry_kernel and raster_kernel (the raster kernel re-arms the bin counters).  A triangle that found a bin
 // full sits in the big list AND possibly in other bins of its span: such frames (DeviceStats::last_big_list > 0 without
 // large triangles) over-count; bench.py reports the big-list length next to the figure.
-__device__ __forceinline__ uint32_t count_record(const uint4* __restrict__ list, size_t ri, int32_t tx, int32_t ty) {
-    const uint4 w0 = list[ri * 3u], w1 = list[ri * 3u + 1u], w2 = list[ri * 3u + 2u];
-    const int32_t tpx0 = tx * TILE, tpy0 = ty * TILE;
-    const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
-    const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
-    if (maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1) return 0u;
+__device__ __forceinline__ uint32_t count_tile_tri(const TileTri& T) {
     uint4 rec[4]; uint32_t box = 0;
-    if (!make_tile_rec(rec, box, w0, w1, w2, tx, ty)) return 0u;
+    if (!make_tile_rec(rec, box, T)) return 0u;
     const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
     const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
     const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
@@ -45,18 +40,27 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     if (tid == 0) lds_sum = 0;
     __syncthreads();
     uint32_t n = 0;
-    const uint4* bins = reinterpret_cast<const uint4*>(H.bin_recs);
+    const uint4* pool = reinterpret_cast<const uint4*>(H.bin_pool);
     const uint32_t nsub = H.count_stride ? 8u : 1u;
     for (uint32_t k = 0; k < nsub; k++) {
         const uint32_t raw = H.bin_count[k * H.count_stride + tile];
         const uint32_t cnt = raw < H.sub_cap ? raw : H.sub_cap;
-        const size_t base = (size_t)tile * H.bin_cap + (size_t)k * H.sub_cap;
-        for (uint32_t i = tid; i < cnt; i += RASTER_THREADS) n += count_record(bins, base + i, (int32_t)tx, (int32_t)ty);
+        for (uint32_t j = tid; j < cnt; j += RASTER_THREADS) {
+            const uint32_t page = (!H.count_stride && j < (uint32_t)BIN_PAGE_RECS) ? tile : P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + k * 8u + (j >> BIN_PAGE_LOG2)];
+            if (page >= PAGE_NONE) continue;
+            const size_t ri = ((size_t)page * BIN_PAGE_RECS + (j & (BIN_PAGE_RECS - 1u))) * 2u;
+            TileTri T;
+            tile_tri_from_bin(T, pool[ri], pool[ri + 1u]);
+            n += count_tile_tri(T);
+        }
     }
     const uint32_t nbig_raw = *H.big_count;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
     const uint4* big = reinterpret_cast<const uint4*>(P.big_recs);
-    for (uint32_t i = tid; i < nbig; i += RASTER_THREADS) n += count_record(big, i, (int32_t)tx, (int32_t)ty);
+    for (uint32_t i = tid; i < nbig; i += RASTER_THREADS) {
+        TileTri T;
+        if (tile_tri_from_big(T, big[(size_t)i * 3u], big[(size_t)i * 3u + 1u], big[(size_t)i * 3u + 2u], (int32_t)tx, (int32_t)ty)) n += count_tile_tri(T);
+    }
     if (n) atomicAdd(&lds_sum, n);
     __syncthreads();
     if (tid == 0 && lds_sum) atomicAdd(&P.frag_stats[1], (unsigned long long)lds_sum);
