@@ -47,8 +47,10 @@ __device__ __forceinline__ uint32_t clamp_box(int32_t bx0, int32_t bx1, int32_t 
     return (uint32_t)bx0 | (((uint32_t)bx1 & 0xFFu) << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
 }
 
-__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T) {
-    const int32_t Pt = 128;                                            // tile origin pixel centre, 1/256 px
+// (opx, opy): the tile's origin in the pixel frame T.X / T.Y are given in -- (0, 0) for a bin record, which is relative to its
+// tile; the tile's position in the target for a big-list record, whose coordinates are absolute.  Wave-uniform.
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
+    const int32_t Ptx = 256 * opx + 128, Pty = 256 * opy + 128;           // tile origin pixel centre, 1/256 px
     int32_t A[3], B[3], Q[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -57,7 +59,7 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
         A[i] = -dy; B[i] = dx;
         const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
         // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22 and |tile origin| < 2^21 in absolute terms)
-        const int64_t e0 = mul24x24(A[i], Pt - T.X[a]) + mul24x24(B[i], Pt - T.Y[a]) + (topleft ? 0 : -1);
+        const int64_t e0 = mul24x24(A[i], Ptx - T.X[a]) + mul24x24(B[i], Pty - T.Y[a]) + (topleft ? 0 : -1);
         int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
         q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
         Q[i] = (int32_t)q;
@@ -92,8 +94,8 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
     const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
     const float inv256 = 1.0f / 256.0f;
-    const float dxt = 0.5f - (float)T.X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
-    const float dyt = 0.5f - (float)T.Y[0] * inv256;
+    const float dxt = ((float)opx + 0.5f) - (float)T.X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
+    const float dyt = ((float)opy + 0.5f) - (float)T.Y[0] * inv256;
     out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
     out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
     out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), T.z0);
@@ -112,23 +114,84 @@ __device__ __forceinline__ void tile_tri_from_bin(TileTri& T, const uint4 w0, co
     T.box = clamp_box((ox + 127) >> 8, (xmax - 128) >> 8, (oy + 127) >> 8, (ymax - 128) >> 8);     // as setup_triangle, in tile-relative pixels
     T.z0 = w1.x; T.zx = w1.y; T.zy = w1.z; T.idk = w1.w; T.boxed = 0u;
 }
-// TriRec (absolute coordinates, big list) -> TileTri for tile (tx, ty); false if its pixel box misses the tile
+// TriRec (big list) -> TileTri for tile (tx, ty), coordinates left absolute (make_tile_rec takes the tile's origin); false if its
+// pixel box misses the tile
 __device__ __forceinline__ bool tile_tri_from_big(TileTri& T, const uint4 w0, const uint4 w1, const uint4 w2, int32_t tx, int32_t ty) {
-    const int32_t opx = tx * TILE, opy = ty * TILE, ox = opx * 256, oy = opy * 256;
+    const int32_t opx = tx * TILE, opy = ty * TILE;
     const int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - opx, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - opx;
     const int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - opy, by1 = (int32_t)(w2.w >> 16) - opy;
     if (bx1 < 0 || bx0 > TILE - 1 || by1 < 0 || by0 > TILE - 1) return false;
     T.box = clamp_box(bx0, bx1, by0, by1);
-    T.X[0] = (int32_t)w0.x - ox; T.Y[0] = (int32_t)w0.y - oy; T.X[1] = (int32_t)w0.z - ox; T.Y[1] = (int32_t)w0.w - oy;
-    T.X[2] = (int32_t)w1.x - ox; T.Y[2] = (int32_t)w1.y - oy;
+    T.X[0] = (int32_t)w0.x; T.Y[0] = (int32_t)w0.y; T.X[1] = (int32_t)w0.z; T.Y[1] = (int32_t)w0.w;
+    T.X[2] = (int32_t)w1.x; T.Y[2] = (int32_t)w1.y;
     T.z0 = w1.z; T.zx = w1.w; T.zy = w2.x; T.idk = w2.y; T.boxed = w2.z & 0x80000000u;
     return true;
 }
-// TriRec words -> tile record of tile (tx, ty) in one step (ordered segments: their records never pass through bins)
-__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2, int32_t tx, int32_t ty) {
-    TileTri T;
-    if (!tile_tri_from_big(T, w0, w1, w2, tx, ty)) { box = 0u; return false; }
-    return make_tile_rec(out, box, T);
+// TriRec (absolute screen coordinates: big list, ordered segments) -> tile record for tile (tx, ty); false if no 8x8 block of the
+// tile can be touched.  Same arithmetic as the TileTri form above with the tile's origin added back (its own copy: fed from one
+// body, the two record forms cost the TRIANGLE-only variants, which live on 64 VGPRs, a dozen spills).
+//   w0 = { Q0, Q1, Q2, A0 }   Q_i = floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
+//   w1 = { A1, A2, B0, B1 }   A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23, fits v_mad_i32_i24)
+//   w2 = { B2, dxt, dyt, z0 } (tile origin pixel centre) - (snapped vertex 0), in pixels (exact), vertex-0 depth
+//   w3 = { zx, zy, idk, mask } mask bits 0..15 = 8x8 blocks the triangle may touch, bit 31 = pixel box applies
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2,
+                                              int32_t tx, int32_t ty) {
+    const int32_t X[3] = {(int32_t)w0.x, (int32_t)w0.z, (int32_t)w1.x}, Y[3] = {(int32_t)w0.y, (int32_t)w0.w, (int32_t)w1.y};
+    const int32_t ox = tx * TILE, oy = ty * TILE;
+    const int32_t Ptx = 256 * ox + 128, Pty = 256 * oy + 128;           // tile origin pixel centre, 1/256 px
+    int32_t A[3], B[3], Q[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int a = i, b = (i + 1) % 3;
+        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
+        A[i] = -dy; B[i] = dx;
+        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
+        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22, |Pt| < 2^21)
+        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
+        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
+        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
+        Q[i] = (int32_t)q;
+    }
+    int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - ox, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - ox;
+    int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - oy, by1 = (int32_t)(w2.w >> 16) - oy;
+    bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+    bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
+    // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
+    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
+    // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
+    // block -- no compares, no branches, nothing on the scalar unit.
+    int32_t c[3], a8[3], b8[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
+        a8[i] = A[i] * BLOCK; b8[i] = B[i] * BLOCK;
+    }
+    uint32_t outside = 0;                               // after the loop: bit (15 - (by*4+bx)) set <=> block outside an edge
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+        int32_t v0 = c[0], v1 = c[1], v2 = c[2];
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) {
+            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)(v0 | v1 | v2), 31);   // (outside << 1) | sign
+            v0 += a8[0]; v1 += a8[1]; v2 += a8[2];
+        }
+        c[0] += b8[0]; c[1] += b8[1]; c[2] += b8[2];
+    }
+    // pixel box -> block box -> mask of the blocks inside it (4 column bits replicated per row, row bits spread to nibbles)
+    const uint32_t cols = ((2u << ((uint32_t)bx1 >> 3)) - 1u) & ~((1u << ((uint32_t)bx0 >> 3)) - 1u);          // bits bx0b..bx1b
+    const uint32_t rows = ((2u << ((uint32_t)by1 >> 3)) - 1u) & ~((1u << ((uint32_t)by0 >> 3)) - 1u);
+    const uint32_t rowsel = ((rows & 1u) * 0xFu) | ((rows & 2u) * 0x78u) | ((rows & 4u) * 0x3C0u) | ((rows & 8u) * 0x1E00u);
+    const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
+    const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
+    const float inv256 = 1.0f / 256.0f;
+    const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
+    const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
+    out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
+    out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
+    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), w1.z);
+    out[3] = make_uint4(w1.w, w2.x, w2.y, mask | (w2.z & 0x80000000u));
+    box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
+    return mask != 0;
 }
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
@@ -308,8 +371,8 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // sub-bins before k, so that flat index i lives in sub-bin #{k >= 1 : i >= seg[k]} at offset i - seg[that].  nullptr: a plain list.
 // bins: `list` is the bin pool and flat index i of the tile's bin lives in pool page pages[...] (LDS copy of the tile's page-table
 // row; the first page of a single-list bin is page `tile` itself); otherwise `list` is a plain TriRec array (the big list).
-template <int KEYED, int TP, int CHUNK, int TEAMS>
-__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, bool bins, uint32_t tile, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
+template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS>
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint32_t tile, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
@@ -335,7 +398,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         uint4 rec[4]; uint32_t box = 0;
         if (ftid < (uint32_t)CHUNK && i < n_total) {
             TileTri T;
-            if (bins) {
+            if (BINS) {
                 // flat index -> (list, slot) -> pool page; both words of the record are requested together
                 uint32_t k = 0, j = i;
                 if (TEAMS > 1 && seg) {
@@ -353,9 +416,13 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             } else {
                 // all three words are requested together: one memory round trip, not two
                 const uint4 w0 = list[(size_t)i * 3u], w1 = list[(size_t)i * 3u + 1u], w2 = list[(size_t)i * 3u + 2u];
-                hit = tile_tri_from_big(T, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
+                const int32_t tpx0 = (int32_t)txl * TILE, tpy0 = (int32_t)tyl * TILE;
+                const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
+                const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
+                hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
+                if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
             }
-            if (hit) hit = make_tile_rec(rec, box, T);
+            if (BINS && hit) hit = make_tile_rec(rec, box, T);
         }
         bool small = false, boxed = false;
         if (hit) {
@@ -533,26 +600,21 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     STAMP(1);
     STAGE_END(1u);
     // the tile's bin, then the list every tile tests (large / clipped / spilled triangles): one copy of the code
-    const uint4* list = reinterpret_cast<const uint4*>(H.bin_pool);
-    uint32_t n_list = count;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        if (n_list) raster_list<KEYED, TP, CHUNK, TEAMS>(list, n_list, pass == 0, tile, lds_pages, (xcd_bins && pass == 0) ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
-                                           qbit0, tid, lane);
-        if (pass == 0) {
-            STAMP(2);
-            if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
-                H.bin_count[tile] = 0;
-                if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[k * H.count_stride + tile] = 0;
-            }
-            // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
-            if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
-            if (!nbig) break;
-            // parameters of this phase are (re)read here, see launder_params
-            list = reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs);
-            n_list = nbig;
-        }
+    // the tile's bin (32-byte records in pool pages), then the list every tile tests (48-byte records: large / clipped / scissor-cut /
+    // spilled triangles).  Two instantiations of raster_list: one body fed from either source has to hold both record forms in
+    // registers on the way to the tile record, which the TRIANGLE-only variants (64 VGPRs) pay with ~20 spills.
+    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+                                                         qbit0, tid, lane);
+    STAMP(2);
+    if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
+        H.bin_count[tile] = 0;
+        if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[k * H.count_stride + tile] = 0;
     }
+    // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
+    if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
+    // parameters of this phase are (re)read here, see launder_params
+    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+                                                         qbit0, tid, lane);
 
     STAMP(3);
     STAGE_END(3u);

@@ -10,9 +10,9 @@
 // Runs between geometry_kernel and raster_kernel (the raster kernel re-arms the bin counters).  A triangle that found a bin
 // full sits in the big list AND possibly in other bins of its span: such frames (DeviceStats::last_big_list > 0 without
 // large triangles) over-count; bench.py reports the big-list length next to the figure.
-__device__ __forceinline__ uint32_t count_tile_tri(const TileTri& T) {
+__device__ __forceinline__ uint32_t count_tile_tri(const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
     uint4 rec[4]; uint32_t box = 0;
-    if (!make_tile_rec(rec, box, T)) return 0u;
+    if (!make_tile_rec(rec, box, T, opx, opy)) return 0u;
     const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
     const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
     const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     const uint4* big = reinterpret_cast<const uint4*>(P.big_recs);
     for (uint32_t i = tid; i < nbig; i += RASTER_THREADS) {
         TileTri T;
-        if (tile_tri_from_big(T, big[(size_t)i * 3u], big[(size_t)i * 3u + 1u], big[(size_t)i * 3u + 2u], (int32_t)tx, (int32_t)ty)) n += count_tile_tri(T);
+        if (tile_tri_from_big(T, big[(size_t)i * 3u], big[(size_t)i * 3u + 1u], big[(size_t)i * 3u + 2u], (int32_t)tx, (int32_t)ty)) n += count_tile_tri(T, (int32_t)tx * TILE, (int32_t)ty * TILE);
     }
     if (n) atomicAdd(&lds_sum, n);
     __syncthreads();

@@ -269,8 +269,9 @@ def test_uniform_update_between_submits(mirhi, oracle, device, scenes):
     res.destroy()
 
 
-def test_big_list_and_bin_spill_paths(mirhi, oracle, device, scenes):
+def test_big_list_and_bin_spill_paths(mirhi, oracle, device, scenes, monkeypatch):
     """Many triangles in one tile overflow its bin into the big list; the result is unchanged (idempotent resolve)."""
+    monkeypatch.setenv("MIRHI_BIN_CAP", "1024")          # records per list (default 4096: 64 pages)
     n = 3000
     rng = np.random.default_rng(5)
     c = np.tile(np.array([[-0.9, -0.9]]), (n, 1)) + rng.uniform(0, 0.02, (n, 2))
@@ -287,9 +288,70 @@ def test_big_list_and_bin_spill_paths(mirhi, oracle, device, scenes):
     res.render(f)
     f.wait()
     assert device.stats().last_big_list > 0          # the bin (capacity << 3000) spilled
+    assert device.stats().last_bin_pages > 0         # and it grew beyond its fixed first page on the way
     got = res.read()
     ref = oracle.render(scene, want_bgra8=False)
     assert np.array_equal(got["prim"], ref["prim"])
+    res.destroy()
+    f.destroy()
+
+
+@pytest.mark.parametrize("pool_pages", [0, 3, 40])
+def test_bin_pool_exhaustion_spills_and_grows(mirhi, oracle, device, scenes, monkeypatch, pool_pages):
+    """The bin pool runs out of dynamic pages (forced: MIRHI_POOL_PAGES): the pages that could not be had send their records to
+    the big list -- the frame is still the oracle's -- and the status word says so.  Without the override the host doubles the
+    pool in front of the next submit and the big list is empty again."""
+    scene = scenes.random_triangles(6000, 320, 200, seed=8, rmin=3, rmax=14)           # ~100 records per tile: 2+ pages each
+    ref = oracle.render(scene, want_bgra8=False)
+    monkeypatch.setenv("MIRHI_POOL_PAGES", str(pool_pages))
+    res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+    f = mirhi.Fence(device)
+    for _ in range(3):
+        res.render(f); f.wait()
+        got = res.read()
+        assert np.array_equal(got["prim"], ref["prim"]) and np.array_equal(got["depth"].view(np.uint32)[ref["prim"] != 0xFFFFFFFF], ref["depth"].view(np.uint32)[ref["prim"] != 0xFFFFFFFF])
+        st = device.stats()
+        assert st.last_status & 4 and st.last_big_list > 0 and st.last_bin_pages >= pool_pages
+    res.destroy()
+    monkeypatch.delenv("MIRHI_POOL_PAGES")
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render(f); f.wait()
+    st = device.stats()
+    assert st.last_status == 0 and st.last_big_list == 0 and 0 < st.last_bin_pages < 1000
+    assert np.array_equal(res.read()["prim"], ref["prim"])
+    res.destroy()
+    f.destroy()
+
+
+def test_pool_grows_after_exhaustion(mirhi, oracle, device, scenes):
+    """A scope with more (triangle, tile) pairs than the initial estimate allows: 8000 triangles that each span up to 4 x 4 tiles
+    of a 512 x 512 target make ~16 pairs each against a budget of 8 per triangle.  First frame: correct through the big list,
+    status bit 2; the submit after the fence has reported it runs on a doubled pool; after a few frames nothing spills any more."""
+    rng = np.random.default_rng(3)
+    n = 8000
+    c = rng.uniform(-0.8, 0.8, (n, 1, 2))
+    ang = rng.uniform(0, 2 * np.pi, (n, 1)) + np.array([[0.0, 2.1, 4.2]])
+    pts = np.zeros((n, 3, 6), dtype=np.float32)
+    pts[:, :, 0] = c[:, :, 0] + 0.22 * np.cos(ang)           # ~56 px radius at 512 px: spans about 4 tiles each way
+    pts[:, :, 1] = c[:, :, 1] + 0.22 * np.sin(ang)
+    pts[:, :, 2] = rng.uniform(0.1, 0.9, (n, 1))
+    pts[:, :, 3:] = rng.uniform(0, 1, (n, 1, 3))
+    d = scenes.DrawSpec(vertices=pts.reshape(-1, 6), stride=24, count=3 * n, cull_mode=scenes.CULL_NONE)
+    scene = scenes.Scene("many-pairs", 512, 512, [d])
+    ref = oracle.render(scene, want_bgra8=False)
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    f = mirhi.Fence(device)
+    seen_exhausted, settled = False, False
+    for _ in range(8):
+        res.render(f); f.wait()
+        assert np.array_equal(res.read()["prim"], ref["prim"])
+        st = device.stats()
+        if st.last_status & 4:
+            seen_exhausted = True
+        elif seen_exhausted:
+            settled = True
+            break
+    assert seen_exhausted and settled
     res.destroy()
     f.destroy()
 
