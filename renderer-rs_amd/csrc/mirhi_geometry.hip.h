@@ -359,16 +359,15 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         uint32_t who;
         const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who, xcd);
         const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
+        // Opening lanes first, as a step of its own: the lane that opens a page and the lanes that wait for it may sit in this very
+        // wave, and lanes on the other side of a branch do not run until this side is through.
+        uint32_t page = PAGE_EMPTY;
+        const bool in_list = act && slot < P.sub_cap;
+        if (in_list && fixed_first && slot < (uint32_t)BIN_PAGE_RECS) page = tile;
+        if (in_list && page == PAGE_EMPTY && (slot & (BIN_PAGE_RECS - 1u)) == 0u) page = bin_page_alloc(P, bin_table_entry(P, tile, xcd, slot));
+        if (in_list && page == PAGE_EMPTY) page = bin_page_wait(P, bin_table_entry(P, tile, xcd, slot));
         if (act) {
-            uint32_t page = PAGE_NONE;
-            if (slot < P.sub_cap) {
-                if (fixed_first && slot < (uint32_t)BIN_PAGE_RECS) page = tile;
-                else {
-                    const uint32_t entry = bin_table_entry(P, tile, xcd, slot);
-                    page = (slot & (BIN_PAGE_RECS - 1u)) == 0u ? bin_page_alloc(P, entry) : bin_page_wait(P, entry);
-                }
-            }
-            if (page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, ty0);
+            if (in_list && page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, ty0);
             else spill = true;       // list full or pool exhausted: the triangle goes to the big list
         }
         if (valid && spill) emit_big(P, t);
