@@ -10,13 +10,15 @@
 // Runs between geometry_kernel and raster_kernel (the raster kernel re-arms the bin counters).  A triangle that found a bin
 // full sits in the big list AND possibly in other bins of its span: such frames (DeviceStats::last_big_list > 0 without
 // large triangles) over-count; bench.py reports the big-list length next to the figure.
-__device__ __forceinline__ uint32_t count_tile_tri(const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
+// (lim_x, lim_y): last pixel of the tile that lies inside the target -- a bin record's box is recomputed from its vertices and may
+// reach beyond the target's edge in the last tile column / row (the raster kernel never stores such pixels)
+__device__ __forceinline__ uint32_t count_tile_tri(const TileTri& T, int32_t lim_x, int32_t lim_y, int32_t opx = 0, int32_t opy = 0) {
     uint4 rec[4]; uint32_t box = 0;
     if (!make_tile_rec(rec, box, T, opx, opy)) return 0u;
     const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
     const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
-    const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
-    const int32_t by0 = (int32_t)((box >> 16) & 0xFF), by1 = (int32_t)(box >> 24);
+    const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = min((int32_t)((box >> 8) & 0xFF), lim_x);
+    const int32_t by0 = (int32_t)((box >> 16) & 0xFF), by1 = min((int32_t)(box >> 24), lim_y);
     int32_t r0 = mad24(B0, by0, mad24(A0, bx0, (int32_t)rec[0].x));
     int32_t r1 = mad24(B1, by0, mad24(A1, bx0, (int32_t)rec[0].y));
     int32_t r2 = mad24(B2, by0, mad24(A2, bx0, (int32_t)rec[0].z));
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     if (tid == 0) lds_sum = 0;
     __syncthreads();
     uint32_t n = 0;
+    const int32_t lim_x = (int32_t)P.width - 1 - (int32_t)(tx * TILE), lim_y = (int32_t)P.height - 1 - (int32_t)(ty * TILE);
     const uint4* pool = reinterpret_cast<const uint4*>(H.bin_pool);
     const uint32_t nsub = H.count_stride ? 8u : 1u;
     for (uint32_t k = 0; k < nsub; k++) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
             const size_t ri = ((size_t)page * BIN_PAGE_RECS + (j & (BIN_PAGE_RECS - 1u))) * 2u;
             TileTri T;
             tile_tri_from_bin(T, pool[ri], pool[ri + 1u]);
-            n += count_tile_tri(T);
+            n += count_tile_tri(T, lim_x, lim_y);
         }
     }
     const uint32_t nbig_raw = *H.big_count;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     const uint4* big = reinterpret_cast<const uint4*>(P.big_recs);
     for (uint32_t i = tid; i < nbig; i += RASTER_THREADS) {
         TileTri T;
-        if (tile_tri_from_big(T, big[(size_t)i * 3u], big[(size_t)i * 3u + 1u], big[(size_t)i * 3u + 2u], (int32_t)tx, (int32_t)ty)) n += count_tile_tri(T, (int32_t)tx * TILE, (int32_t)ty * TILE);
+        if (tile_tri_from_big(T, big[(size_t)i * 3u], big[(size_t)i * 3u + 1u], big[(size_t)i * 3u + 2u], (int32_t)tx, (int32_t)ty)) n += count_tile_tri(T, lim_x, lim_y, (int32_t)tx * TILE, (int32_t)ty * TILE);
     }
     if (n) atomicAdd(&lds_sum, n);
     __syncthreads();
