@@ -1067,7 +1067,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     hipStream_t stream = dev->lanes[cmd->lane];
     HIP_TRY(hipStreamSynchronize(stream));
     size_t total_draws = 0, max_tiles = 0, max_pages = 0, max_big = 0;
-    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages; bool xcd_bins; };
+    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };
     std::vector<Geo> geo;
     for (auto& pass : cmd->passes) {
         const mirhi_image* ci = pass.info.color_image;
@@ -1092,9 +1092,14 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         size_t pairs = std::max(std::max(std::min<size_t>(8 * tris, 262144), std::min<size_t>(3 * tris, 786432)), 3 * tris / 2);
         pairs *= cmd->ws.pool_scale;
         if (pairs > 16 * tris) pairs = 16 * tris;                        // (a binned triangle spans at most 4 x 4 tiles)
-        g.fixed_pages = g.xcd_bins ? 0u : (uint32_t)tiles;
-        size_t pages = g.fixed_pages + pairs / BIN_PAGE_RECS + tiles * (g.xcd_bins ? 2 : 1) + 64;
-        if (getenv("MIRHI_POOL_PAGES")) pages = g.fixed_pages + (size_t)atoi(getenv("MIRHI_POOL_PAGES"));      // (pool-exhaustion test)
+        // fixed pages per tile: what the average density fills (x 1.3 for triangles that straddle tiles), at least one, at most eight --
+        // a uniform mesh (the 1M-triangle grid: 123 per tile) then bins without a single allocation, a concentrated one (the
+        // dancer asset) opens pages where its triangles are
+        g.fixed_per_tile = g.xcd_bins ? 0u : (uint32_t)std::min<size_t>(8, std::max<size_t>(1, tiles ? (13 * tris / (10 * tiles) + BIN_PAGE_RECS - 1) / BIN_PAGE_RECS : 1));
+        if (getenv("MIRHI_FIXED_PAGES") && !g.xcd_bins) g.fixed_per_tile = (uint32_t)std::min(8, std::max(1, atoi(getenv("MIRHI_FIXED_PAGES"))));   // (tests, A/B runs)
+        g.fixed_pages = g.fixed_per_tile * (uint32_t)tiles;
+        size_t pages = g.fixed_pages + ((pairs / BIN_PAGE_RECS + tiles * (g.xcd_bins ? 2 : 1) + 64 + 7) & ~(size_t)7);
+        if (getenv("MIRHI_POOL_PAGES")) pages = g.fixed_pages + 8 * (((size_t)atoi(getenv("MIRHI_POOL_PAGES")) + 7) / 8);      // (pool-exhaustion test)
         g.big_cap = pass.total_tris + pass.total_tris / 4 + 1024;
         geo.push_back(g);
         total_draws += pass.draws.size();
@@ -1114,7 +1119,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     w.grow_pool = false;
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
     size_t counter_bytes = w.counters_words * 4;
-    const size_t want_words = 8 * max_tiles + 8;          // bin counters (one per tile, or one per tile and XCD), big-list counters, pool counter
+    const size_t want_words = 8 * max_tiles + 32 + 8 * POOL_COUNTER_STRIDE;   // bin counters (one per tile, or per tile and XCD), big-list counters, pool counters
     const bool fresh = !(w.counters && counter_bytes >= want_words * 4);
     if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
     w.counters_words = counter_bytes / 4;
@@ -1240,8 +1245,9 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         if (pass.carry_out) P.depth_store = 1u;
         P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
         P.bin_pool = w.bin_pool; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
-        P.bin_table = w.bin_table; P.pool_next = w.big_counts + 2;
-        P.pool_dyn_base = g.fixed_pages; P.pool_dyn_pages = (uint32_t)(pool_pages - g.fixed_pages);
+        P.bin_table = w.bin_table; P.pool_next = w.big_counts + 32;
+        P.pool_dyn_base = g.fixed_pages; P.pool_dyn_pages = (uint32_t)((pool_pages - g.fixed_pages) / 8);      // per XCD
+        P.fixed_recs = g.fixed_per_tile * BIN_PAGE_RECS;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
         P.frag_stats = dev->frag_stats;

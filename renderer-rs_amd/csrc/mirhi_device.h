@@ -26,6 +26,7 @@ constexpr float GUARD_PX = 16000.0f;  // guard band: snapped coordinates stay in
 constexpr int BIN_PAGE_RECS = 64;     // records per bin page (2 KB)
 constexpr int BIN_PAGE_LOG2 = 6;
 constexpr int BIN_TABLE_ROW = 64;     // page-table entries per tile: 64 pages of one list, or 8 pages for each of 8 per-XCD lists
+constexpr int POOL_COUNTER_STRIDE = 32;        // words between the per-XCD pool counters (128 B)
 constexpr uint32_t PAGE_EMPTY = 0xFFFFFFFFu;   // table entry not (yet) published
 constexpr uint32_t PAGE_NONE = 0xFFFFFFFEu;    // the pool was exhausted when this page was asked for: its records go to the big list
 constexpr uint32_t NO_PRIM = 0xFFFFFFFFu;
@@ -131,8 +132,12 @@ struct PassParams {
     // workspace
     BinRec*   bin_pool; uint32_t* bin_count; uint32_t bin_cap;     // bin_cap: records a tile's bin can hold (all of its lists)
     uint32_t* bin_table;              // [tiles][BIN_TABLE_ROW] pool page of the list's p-th page (PAGE_EMPTY until published)
-    uint32_t* pool_next;              // dynamic pages handed out so far in this scope (re-armed by the raster kernel)
-    uint32_t  pool_dyn_base, pool_dyn_pages;   // dynamic pages are pool pages [pool_dyn_base, pool_dyn_base + pool_dyn_pages)
+    uint32_t* pool_next;              // [8][POOL_COUNTER_STRIDE] dynamic pages handed out in this scope by the waves of each XCD (re-armed by
+                                      // the raster kernel): one counter per XCD, a cache line apart -- a single counter that every XCD adds
+                                      // to ping-pongs between their L2s (C4: geometry 57 -> 132 us)
+    uint32_t  pool_dyn_base, pool_dyn_pages;   // XCD x hands out pool pages [pool_dyn_base + x * pool_dyn_pages, ... + pool_dyn_pages)
+    uint32_t  fixed_recs;             // slots [0, fixed_recs) of a tile's single list live in the tile's own fixed pages (page = tile *
+                                      // fixed_recs / 64 + slot / 64): 64 x the pages the scope's average triangle density fills, 0 with per-XCD lists
     BigRec*   big_recs; uint32_t* big_count; uint32_t big_cap;
     uint32_t* big_count_next;         // the other parity's counter: zeroed by this scope for the next one
     uint32_t* prim_draw;              // per primitive of the scope (index prim - first_prim): its draw, written by the geometry kernel when
@@ -166,6 +171,7 @@ struct RasterHead {
     uint32_t* bin_count; const BinRec* bin_pool; uint32_t* big_count;
     uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;
     uint32_t sub_cap, count_stride;   // per-XCD bins (PassParams); read by the two-team variant only
+    uint32_t fixed_recs;              // PassParams::fixed_recs
 };
 
 }  // namespace mirhi

@@ -288,8 +288,9 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// bin pages.  A list's slot s lives in its page s / 64 at offset s % 64.  Without per-XCD lists the first page of a tile has a
-// fixed place (pool page = tile): the usual bin costs no allocation.  Any other page is taken from the pool by the ONE lane
+// bin pages.  A list's slot s lives in its page s / 64 at offset s % 64.  Without per-XCD lists the first fixed_recs / 64 pages of
+// a tile have a fixed place in the pool (as many as the scope's average density fills): the usual bin costs no allocation.  Any
+// other page is taken from the pool by the ONE lane
 // whose slot is the page's first (s % 64 == 0) and published in the tile's row of the page table; the lanes that drew the
 // other slots of that page (this wave or another) read the entry until it is there.  Waiting is safe: the publishing lane has
 // executed its reservation (its slot is smaller), and a wave publishes every page of a batch of reservations before it waits
@@ -298,13 +299,16 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
 __device__ __forceinline__ uint32_t bin_table_entry(ParamsRef P, uint32_t tile, uint32_t xcd, uint32_t slot) {
     return tile * (uint32_t)BIN_TABLE_ROW + (P.count_stride ? xcd * 8u : 0u) + (slot >> BIN_PAGE_LOG2);
 }
-__device__ __forceinline__ uint32_t bin_page_alloc(ParamsRef P, uint32_t entry) {
-    const uint32_t id = atomicAdd(P.pool_next, 1u);
-    uint32_t page = P.pool_dyn_base + id;
-    if (id >= P.pool_dyn_pages) {      // pool exhausted: the page's records take the big list; the host grows the pool for the next submit
-        page = PAGE_NONE;
-        __hip_atomic_fetch_or(P.status, STATUS_POOL_EXHAUSTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ uint32_t bin_page_alloc(ParamsRef P, uint32_t entry, uint32_t xcd) {
+    // this XCD's share of the pool first, then the others' (rare: the shares are equal and the load is spread by the dispatcher)
+    uint32_t page = PAGE_NONE;
+    for (uint32_t d = 0; d < 8u && page == PAGE_NONE; d++) {
+        const uint32_t x = (xcd + d) & 7u;
+        const uint32_t id = atomicAdd(&P.pool_next[x * (uint32_t)POOL_COUNTER_STRIDE], 1u);
+        if (id < P.pool_dyn_pages) page = P.pool_dyn_base + x * P.pool_dyn_pages + id;
     }
+    // pool exhausted: the page's records take the big list; the host grows the pool for the next submit
+    if (page == PAGE_NONE) __hip_atomic_fetch_or(P.status, STATUS_POOL_EXHAUSTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&P.bin_table[entry], page, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return page;
 }
@@ -330,8 +334,9 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                                                    uint32_t* lds_meta, uint16_t* lds_owner) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t xcd = P.count_stride ? xcd_of_wave() : 0u;        // wave-uniform
-    const bool fixed_first = P.count_stride == 0u;                     // the first page of a list has a fixed place
+    const uint32_t hw_xcd = xcd_of_wave();                           // wave-uniform
+    const uint32_t xcd = P.count_stride ? hw_xcd : 0u;               // the list this wave appends to (per-XCD bins)
+    const uint32_t fixed_recs = P.fixed_recs;                        // slots below live in the tile's own fixed pages
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
     bool spill = false;
     if (valid) {
@@ -363,8 +368,8 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         // wave, and lanes on the other side of a branch do not run until this side is through.
         uint32_t page = PAGE_EMPTY;
         const bool in_list = act && slot < P.sub_cap;
-        if (in_list && fixed_first && slot < (uint32_t)BIN_PAGE_RECS) page = tile;
-        if (in_list && page == PAGE_EMPTY && (slot & (BIN_PAGE_RECS - 1u)) == 0u) page = bin_page_alloc(P, bin_table_entry(P, tile, xcd, slot));
+        if (in_list && slot < fixed_recs) page = (tile * fixed_recs + slot) >> BIN_PAGE_LOG2;
+        if (in_list && page == PAGE_EMPTY && (slot & (BIN_PAGE_RECS - 1u)) == 0u) page = bin_page_alloc(P, bin_table_entry(P, tile, xcd, slot), hw_xcd);
         if (in_list && page == PAGE_EMPTY) page = bin_page_wait(P, bin_table_entry(P, tile, xcd, slot));
         if (act) {
             if (in_list && page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, ty0);
@@ -422,10 +427,10 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             const uint32_t p = (it0 + k) * GEOM_THREADS + lane;
             const uint32_t s = (uint32_t)__shfl((int)slot[k], (int)(aux[k] & 0xFFu)) + (aux[k] >> 8);
             slot[k] = s; aux[k] = PAGE_EMPTY;
-            if (p < total && s < P.sub_cap && (s & (BIN_PAGE_RECS - 1u)) == 0u && !(fixed_first && s == 0u)) {
+            if (p < total && s < P.sub_cap && (s & (BIN_PAGE_RECS - 1u)) == 0u && s >= fixed_recs) {
                 const uint32_t o = lds_owner[p], kk = o >> 8;
                 const uint32_t tile = (lds_meta[o & 0xFFu] & 0x7FFFFFFFu) + (kk / MAX_BIN_SPAN) * P.tiles_x + (kk % MAX_BIN_SPAN);
-                aux[k] = bin_page_alloc(P, bin_table_entry(P, tile, xcd, s));
+                aux[k] = bin_page_alloc(P, bin_table_entry(P, tile, xcd, s), hw_xcd);
             }
         }
 #pragma unroll
@@ -438,7 +443,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                 const uint32_t s = slot[k];
                 uint32_t page = PAGE_NONE;
                 if (s < P.sub_cap) {
-                    if (fixed_first && s < (uint32_t)BIN_PAGE_RECS) page = tile;
+                    if (s < fixed_recs) page = (tile * fixed_recs + s) >> BIN_PAGE_LOG2;
                     else if (aux[k] != PAGE_EMPTY) page = aux[k];
                     else page = bin_page_wait(P, bin_table_entry(P, tile, xcd, s));
                 }

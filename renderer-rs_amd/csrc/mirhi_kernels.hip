@@ -82,7 +82,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
     if (P.ordered_recs) {           // ordered segment: fragments in primitive order (blending)
-        const RasterHead HO = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.bin_cap, 0u};
+        const RasterHead HO = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.bin_cap, 0u, 0u};
         const dim3 og(P.tiles_x, rows), ob(ORDERED_THREADS);
         if (programs == 2) MIRHI_LAUNCH(ordered_kernel<2>, og, ob, stream, t, dev_params, HO);
         else if (programs == 3) MIRHI_LAUNCH(ordered_kernel<3>, og, ob, stream, t, dev_params, HO);
@@ -93,7 +93,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
-    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride};
+    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
     if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream, t);          // (the host keeps tp_max_area = 0 for predicate scopes)
     else if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) {
         if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream, t);
@@ -106,7 +106,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0 || P.ordered_recs) return hipSuccess;
-    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride};
+    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
     MIRHI_LAUNCH(fragment_count_kernel, dim3(P.tiles_x, rows), dim3(RASTER_THREADS), stream, t, dev_params, H);
     return hipGetLastError();
 }

@@ -372,7 +372,7 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // bins: `list` is the bin pool and flat index i of the tile's bin lives in pool page pages[...] (LDS copy of the tile's page-table
 // row; the first page of a single-list bin is page `tile` itself); otherwise `list` is a plain TriRec array (the big list).
 template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS>
-__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint32_t tile, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
+__device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint32_t tile, uint32_t fixed_recs, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
                                             ParamsRef P, PixelState& st, uint32_t qbit0, uint32_t tid,
@@ -406,7 +406,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
                     for (uint32_t q = 1; q < 8u; q++) k += i >= seg[q] ? 1u : 0u;
                     j = i - seg[k];
                 }
-                const uint32_t page = (!seg && j < (uint32_t)BIN_PAGE_RECS) ? tile : pages[k * 8u + (j >> BIN_PAGE_LOG2)];
+                const uint32_t page = j < fixed_recs ? (tile * fixed_recs + j) >> BIN_PAGE_LOG2 : pages[k * 8u + (j >> BIN_PAGE_LOG2)];
                 hit = page < PAGE_NONE;            // (a page the exhausted pool could not supply: its records are in the big list)
                 if (hit) {
                     const uint32_t ri = (page * (uint32_t)BIN_PAGE_RECS + (j & (BIN_PAGE_RECS - 1u))) * 2u;      // (pools stay far below 2^32 words)
@@ -528,9 +528,9 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     }
     const uint32_t count = count_raw < H.bin_cap ? count_raw : H.bin_cap;
     const uint32_t nbig = nbig_raw < H.big_cap ? nbig_raw : H.big_cap;
-    // The tile's row of the page table is needed only beyond the first (fixed) page of a single-list bin, or with per-XCD lists.
+    // The tile's row of the page table is needed only beyond the tile's fixed pages (there are none with per-XCD lists).
     __shared__ uint32_t lds_pages[BIN_TABLE_ROW];
-    const bool need_pages = xcd_bins || count > (uint32_t)BIN_PAGE_RECS;
+    const bool need_pages = count > H.fixed_recs;
     if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) lds_pages[threadIdx.x] = P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x];
     // (Letting the second team leave tiles whose lists fit one staging pass was measured: the scopes that get this variant
     // leave most of the chip idle anyway, and those tiles then lose the split resolve: dancer 43 -> 46 us, 49 -> 57 us textured.)
@@ -543,8 +543,13 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     if (tid == 0 && team == 0 && tile == 0) {
         *P.big_count_next = 0;                              // the next scope on this workspace appends to the other counter
         P.status[1] = nbig_raw;
-        P.status[2] = *P.pool_next;                         // dynamic bin pages of this scope; no raster workgroup reads the counter,
-        *P.pool_next = 0;                                   // and the next geometry kernel on this workspace is ordered behind this kernel
+        uint32_t pages_used = 0;                            // dynamic bin pages of this scope; no raster workgroup reads the counters,
+        for (uint32_t x = 0; x < 8u; x++) {                 // and the next geometry kernel on this workspace is ordered behind this kernel
+            const uint32_t c = P.pool_next[x * (uint32_t)POOL_COUNTER_STRIDE];
+            pages_used += c < P.pool_dyn_pages ? c : P.pool_dyn_pages;
+            P.pool_next[x * (uint32_t)POOL_COUNTER_STRIDE] = 0;
+        }
+        P.status[2] = pages_used;
     }
 
     if (count == 0u && nbig == 0u) {
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     // the tile's bin (32-byte records in pool pages), then the list every tile tests (48-byte records: large / clipped / scissor-cut /
     // spilled triangles).  Two instantiations of raster_list: one body fed from either source has to hold both record forms in
     // registers on the way to the tile record, which the TRIANGLE-only variants (64 VGPRs) pay with ~20 spills.
-    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, H.fixed_recs, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
     STAMP(2);
     if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
     // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
     if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
     // parameters of this phase are (re)read here, see launder_params
-    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, 0u, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
 
     STAMP(3);

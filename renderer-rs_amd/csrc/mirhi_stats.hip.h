@@ -49,7 +49,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
         const uint32_t raw = H.bin_count[k * H.count_stride + tile];
         const uint32_t cnt = raw < H.sub_cap ? raw : H.sub_cap;
         for (uint32_t j = tid; j < cnt; j += RASTER_THREADS) {
-            const uint32_t page = (!H.count_stride && j < (uint32_t)BIN_PAGE_RECS) ? tile : P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + k * 8u + (j >> BIN_PAGE_LOG2)];
+            const uint32_t page = j < H.fixed_recs ? (tile * H.fixed_recs + j) >> BIN_PAGE_LOG2 : P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + k * 8u + (j >> BIN_PAGE_LOG2)];
             if (page >= PAGE_NONE) continue;
             const size_t ri = ((size_t)page * BIN_PAGE_RECS + (j & (BIN_PAGE_RECS - 1u))) * 2u;
             TileTri T;

@@ -304,6 +304,7 @@ def test_bin_pool_exhaustion_spills_and_grows(mirhi, oracle, device, scenes, mon
     scene = scenes.random_triangles(6000, 320, 200, seed=8, rmin=3, rmax=14)           # ~100 records per tile: 2+ pages each
     ref = oracle.render(scene, want_bgra8=False)
     monkeypatch.setenv("MIRHI_POOL_PAGES", str(pool_pages))
+    monkeypatch.setenv("MIRHI_FIXED_PAGES", "1")         # (the density of this scene would earn every tile two fixed pages)
     res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
     f = mirhi.Fence(device)
     for _ in range(3):
@@ -314,7 +315,7 @@ def test_bin_pool_exhaustion_spills_and_grows(mirhi, oracle, device, scenes, mon
         assert st.last_status & 4 and st.last_big_list > 0 and st.last_bin_pages >= pool_pages
     res.destroy()
     monkeypatch.delenv("MIRHI_POOL_PAGES")
-    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res = mirhi.SceneResources(device, scene, want_prim=True)            # (still one fixed page per tile)
     res.render(f); f.wait()
     st = device.stats()
     assert st.last_status == 0 and st.last_big_list == 0 and 0 < st.last_bin_pages < 1000
