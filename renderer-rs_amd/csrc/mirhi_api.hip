@@ -1090,7 +1090,6 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         // that needs more spills into the big list (correct, slower) and the pool is doubled for the next submit.
         const size_t tris = pass.total_tris - pass.first_tri;
         size_t pairs = std::max(std::max(std::min<size_t>(8 * tris, 262144), std::min<size_t>(3 * tris, 786432)), 3 * tris / 2);
-        pairs *= cmd->ws.pool_scale;
         if (pairs > 16 * tris) pairs = 16 * tris;                        // (a binned triangle spans at most 4 x 4 tiles)
         // fixed pages per tile: what the average density fills (x 1.3 for triangles that straddle tiles), at least one, at most eight --
         // a uniform mesh (the 1M-triangle grid: 123 per tile) then bins without a single allocation, a concentrated one (the
@@ -1098,7 +1097,11 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         g.fixed_per_tile = g.xcd_bins ? 0u : (uint32_t)std::min<size_t>(8, std::max<size_t>(1, tiles ? (13 * tris / (10 * tiles) + BIN_PAGE_RECS - 1) / BIN_PAGE_RECS : 1));
         if (getenv("MIRHI_FIXED_PAGES") && !g.xcd_bins) g.fixed_per_tile = (uint32_t)std::min(8, std::max(1, atoi(getenv("MIRHI_FIXED_PAGES"))));   // (tests, A/B runs)
         g.fixed_pages = g.fixed_per_tile * (uint32_t)tiles;
-        size_t pages = g.fixed_pages + ((pairs / BIN_PAGE_RECS + tiles * (g.xcd_bins ? 2 : 1) + 64 + 7) & ~(size_t)7);
+        // dynamic part: the estimated pairs that the fixed pages will not take (they take at most half of it when the triangles sit
+        // in a part of the frame), never less than a quarter of the estimate, plus a partly filled page for one tile in four
+        const size_t fixed_capacity = (size_t)g.fixed_pages * BIN_PAGE_RECS;
+        const size_t dyn_records = std::max(pairs > fixed_capacity / 2 ? pairs - fixed_capacity / 2 : 0, pairs / 4) * cmd->ws.pool_scale;
+        size_t pages = g.fixed_pages + ((dyn_records / BIN_PAGE_RECS + tiles * (g.xcd_bins ? 8 : 1) / 4 + 64 + 7) & ~(size_t)7);
         if (getenv("MIRHI_POOL_PAGES")) pages = g.fixed_pages + 8 * (((size_t)atoi(getenv("MIRHI_POOL_PAGES")) + 7) / 8);      // (pool-exhaustion test)
         g.big_cap = pass.total_tris + pass.total_tris / 4 + 1024;
         geo.push_back(g);
