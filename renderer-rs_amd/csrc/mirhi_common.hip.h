@@ -69,8 +69,10 @@ __device__ __forceinline__ f3 mul3(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a
 __device__ __forceinline__ f3 cross3(f3 a, f3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
-__device__ __forceinline__ f3 normalize3(f3 a) { const float inv = 1.0f / sqrtf(dot3(a, a)); return {a.x * inv, a.y * inv, a.z * inv}; }
+// IEEE sqrt and division, bit for bit the oracle's sqrtf / "/" (mirhi_exact.hip.h: same results as the compiler's expansions at a
+// third of their instructions)
+__device__ __forceinline__ float length3(f3 a) { return sqrt_rn_nb(dot3(a, a)); }
+__device__ __forceinline__ f3 normalize3(f3 a) { const float inv = inv_sqrt_rn_nb(dot3(a, a)); return {a.x * inv, a.y * inv, a.z * inv}; }
 __device__ __forceinline__ float saturatef(float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; }
 
 #endif  // MIRHI_COMMON_HIP_H

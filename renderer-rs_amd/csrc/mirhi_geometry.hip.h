@@ -55,7 +55,7 @@ __device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         if (!(c[i].w > 0.0f)) return false;
-        const float iw = 1.0f / c[i].w;
+        const float iw = rcp_rn(c[i].w);                                  // IEEE 1/w (mirhi_exact.hip.h: verified for every binary32)
         const float xs = (c[i].x * iw) * D.hw + D.cx;                     // Vulkan viewport transform
         const float ys = (c[i].y * iw) * D.hh + D.cy;
         const float zs = (c[i].z * iw) * D.dscale + D.dmin;
@@ -81,8 +81,8 @@ __device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 
     const float fx2 = (float)(t.X[2] - t.X[0]) * inv256, fy2 = (float)(t.Y[2] - t.Y[0]) * inv256;
     const float area = fx1 * fy2 - fx2 * fy1;
     const float dz1 = z[1] - z[0], dz2 = z[2] - z[0];
-    t.zx = (dz1 * fy2 - dz2 * fy1) / area;
-    t.zy = (dz2 * fx1 - dz1 * fx2) / area;
+    t.zx = div_rn(dz1 * fy2 - dz2 * fy1, area);                           // IEEE quotients
+    t.zy = div_rn(dz2 * fx1 - dz1 * fx2, area);
     t.z0 = z[0];
     const int32_t xmin = min(t.X[0], min(t.X[1], t.X[2])), xmax = max(t.X[0], max(t.X[1], t.X[2]));
     const int32_t ymin = min(t.Y[0], min(t.Y[1], t.Y[2])), ymax = max(t.Y[0], max(t.Y[1], t.Y[2]));
@@ -159,7 +159,7 @@ __device__ __forceinline__ void clip_and_emit(ParamsRef P, DrawRef D, f4 (*poly)
             if (ina != inb) {
                 f4 p, q; float dp, dq;
                 if (ina) { p = a; q = b; dp = da; dq = db; } else { p = b; q = a; dp = db; dq = da; }
-                const float tt = dp / (dp - dq);
+                const float tt = div_rn(dp, dp - dq);
                 tmp[m++] = {p.x + tt * (q.x - p.x), p.y + tt * (q.y - p.y), p.z + tt * (q.z - p.z), p.w + tt * (q.w - p.w)};
             }
         }

@@ -27,6 +27,7 @@
 
 namespace mirhi {
 
+#include "mirhi_exact.hip.h"
 #include "mirhi_common.hip.h"
 #include "mirhi_geometry.hip.h"
 #include "mirhi_shading.hip.h"

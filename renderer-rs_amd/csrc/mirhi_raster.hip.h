@@ -470,7 +470,10 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // workgroups, unlike sharing a tile between workgroups ("measured and not adopted").  On frames that already
 // fill the chip the wider workgroups only cost occupancy (C4 raster 109 -> 156 us, C5 202 -> 272 us), hence the host's choice.
 template <int PROGS, int KEYED, int TP, int TEAMS = 1>
-__global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? 5 : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+#ifndef MIRHI_PROGS2_WAVES
+#define MIRHI_PROGS2_WAVES 5
+#endif
+__global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? MIRHI_PROGS2_WAVES : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     // mesh variants stage with all four waves: their small records are resolved while staging (triangle-parallel), so a
     // hot tile's serial chain is one pass per CHUNK records; the sparse variants keep 192 (LDS per workgroup bounds

@@ -24,9 +24,10 @@ __device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgc
 __device__ __forceinline__ f3 fnormalize3(f3 a) { const float r = frsq(dot3(a, a)); return {a.x * r, a.y * r, a.z * r}; }
 #pragma clang fp contract(off)
 
+// (scales the light's colour and feeds no exponent: the 1-ulp reciprocals are far inside the 1e-4 colour bound)
 __device__ __forceinline__ float attenuation(float distance, float radius) {          // lights.hlsli:63-73
-    const float att = 1.0f / (distance * distance + 1.0f);
-    float falloff = saturatef(1.0f - distance / radius);
+    const float att = __builtin_amdgcn_rcpf(distance * distance + 1.0f);
+    float falloff = saturatef(1.0f - distance * __builtin_amdgcn_rcpf(radius));
     falloff = falloff * falloff;
     return att * falloff;
 }
@@ -131,7 +132,7 @@ __device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc
     const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
     const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
     const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
-    const float inv = FAST ? __builtin_amdgcn_rcpf((l0 + l1) + l2) : 1.0f / ((l0 + l1) + l2);
+    const float inv = FAST ? __builtin_amdgcn_rcpf((l0 + l1) + l2) : rcp_rn_nb((l0 + l1) + l2);
     b[0] = l0 * inv; b[1] = l1 * inv; b[2] = l2 * inv;
 }
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, fl
     const float l0 = ax[1] * ay[2] - ax[2] * ay[1];
     const float l1 = ax[2] * ay[0] - ax[0] * ay[2];
     const float l2 = ax[0] * ay[1] - ax[1] * ay[0];
-    const float inv = 1.0f / ((l0 + l1) + l2);
+    const float inv = rcp_rn_nb((l0 + l1) + l2);
     const float b[3] = {l0 * inv, l1 * inv, l2 * inv};
     const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
     return {o.x, o.y, o.z, 1.0f};
@@ -167,13 +168,13 @@ __device__ __forceinline__ float distribution_ggx(float NdotH, float roughness) 
     const float NdotH2 = NdotH * NdotH;
     float denom = NdotH2 * (a2 - 1.0f) + 1.0f;
     denom = (PBR_PI * denom) * denom;
-    return a2 / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+    return div_rn_nb(a2, denom > PBR_EPSILON ? denom : PBR_EPSILON);
 }
 __device__ __forceinline__ float geometry_schlick_ggx(float NdotV, float roughness) {   // pbr.hlsli:83-93
     const float r = roughness + 1.0f;
-    const float k = (r * r) / 8.0f;
+    const float k = (r * r) * 0.125f;              // (exact: a power of two)
     const float denom = NdotV * (1.0f - k) + k;
-    return NdotV / (denom > PBR_EPSILON ? denom : PBR_EPSILON);
+    return div_rn_nb(NdotV, denom > PBR_EPSILON ? denom : PBR_EPSILON);
 }
 struct PbrMaterial { f3 albedo; float metallic, roughness; };
 __device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const PbrMaterial& m) {   // pbr.hlsli:292-333
@@ -190,10 +191,10 @@ __device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const Pb
     const f3 kD = {(1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om};
     const float ndg = NDF * G;
     const float denominator = (4.0f * NdotV) * NdotL + PBR_EPSILON;
-    const f3 specular = {(ndg * F.x) / denominator, (ndg * F.y) / denominator, (ndg * F.z) / denominator};
-    return {(((kD.x * m.albedo.x) / PBR_PI + specular.x) * radiance.x) * NdotL,
-            (((kD.y * m.albedo.y) / PBR_PI + specular.y) * radiance.y) * NdotL,
-            (((kD.z * m.albedo.z) / PBR_PI + specular.z) * radiance.z) * NdotL};
+    const f3 specular = {div_rn_nb(ndg * F.x, denominator), div_rn_nb(ndg * F.y, denominator), div_rn_nb(ndg * F.z, denominator)};
+    return {((div_rn_nb(kD.x * m.albedo.x, PBR_PI) + specular.x) * radiance.x) * NdotL,
+            ((div_rn_nb(kD.y * m.albedo.y, PBR_PI) + specular.y) * radiance.y) * NdotL,
+            ((div_rn_nb(kD.z * m.albedo.z, PBR_PI) + specular.z) * radiance.z) * NdotL};
 }
 
 // pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
@@ -237,7 +238,7 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
         const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
         const float intensity = ldcf(cb(D.lights), 12);
         const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
-        lighting = add3(lighting, pbr_direct(N, V, normalize3({-dir.x, -dir.y, -dir.z}), scale3(color, intensity), m));
+        if (intensity != 0.0f) lighting = add3(lighting, pbr_direct(N, V, normalize3({-dir.x, -dir.y, -dir.z}), scale3(color, intensity), m));
     }
     const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
     const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
@@ -249,8 +250,10 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
         const float intensity = ldcf(Lp, 28);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = scale3(lv, 1.0f / dist);
-        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(color, intensity), attenuation(dist, radius)), m));
+        const float att = attenuation(dist, radius);
+        if (__ballot(att > 0.0f) == 0ull) continue;                          // out of the light's reach: exact zeros (see model_full)
+        const f3 L = scale3(lv, rcp_rn_nb(dist));
+        lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(color, intensity), att), m));
     }
     for (uint32_t j = 0; j < numSpot; j++) {
         const CBytePtr Ls = cb(D.spot_lights) + 48u * j;
@@ -262,11 +265,12 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
         const float intensity = ldcf(Ls, 44);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = scale3(lv, 1.0f / dist);
+        const f3 L = scale3(lv, rcp_rn_nb(dist));
         const float datt = attenuation(dist, 50.0f);
         const f3 sd = normalize3(sdir);
         const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);
-        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        const float satt = saturatef(div_rn_nb(cosAngle - outerCos, innerCos - outerCos));
+        if (__ballot(datt * satt > 0.0f) == 0ull) continue;
         lighting = add3(lighting, pbr_direct(N, V, L, scale3(scale3(scale3(color, intensity), datt), satt), m));
     }
     const float up = N.y * 0.5f + 0.5f;                                                 // CalculateHemisphereAmbient pbr.hlsli:483-492
@@ -353,8 +357,12 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
         const f3 dir = {ldcf(cb(D.lights), 0), ldcf(cb(D.lights), 4), ldcf(cb(D.lights), 8)};
         const float intensity = ldcf(cb(D.lights), 12);
         const f3 color = {ldcf(cb(D.lights), 16), ldcf(cb(D.lights), 20), ldcf(cb(D.lights), 24)};
-        const f3 L = normalize3({-dir.x, -dir.y, -dir.z});
-        lighting = add3(lighting, blinn_phong(L, V, N, scale3(color, intensity), albedo, shininess));
+        // (a light of intensity 0 adds exactly +0 to every channel: skipped, wave-uniformly -- BASELINE's Phong configs run without
+        // a directional light)
+        if (intensity != 0.0f) {
+            const f3 L = normalize3({-dir.x, -dir.y, -dir.z});
+            lighting = add3(lighting, blinn_phong(L, V, N, scale3(color, intensity), albedo, shininess));
+        }
     }
     const uint32_t numPoint = D.point_lights ? ldcu(cb(D.lights), 32) : 0u;
     const uint32_t numSpot = D.spot_lights ? ldcu(cb(D.lights), 36) : 0u;
@@ -366,8 +374,12 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
         const float intensity = ldcf(Lp, 28);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = scale3(lv, 1.0f / dist);
-        const f3 lc = scale3(scale3(color, intensity), attenuation(dist, radius));
+        // beyond its radius the light's falloff is exactly 0, and so is everything it adds: a wave none of whose pixels the light
+        // reaches skips the rest of the iteration (the other lanes of a wave that goes on add their exact zeros)
+        const float att = attenuation(dist, radius);
+        if (__ballot(att > 0.0f) == 0ull) continue;
+        const f3 L = scale3(lv, rcp_rn_nb(dist));
+        const f3 lc = scale3(scale3(color, intensity), att);
         lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
     }
     for (uint32_t j = 0; j < numSpot; j++) {                                 // CalculateSpotLight :202-231
@@ -380,11 +392,12 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
         const float intensity = ldcf(Ls, 44);
         const f3 lv = sub3(pos, worldPos);
         const float dist = length3(lv);
-        const f3 L = scale3(lv, 1.0f / dist);
+        const f3 L = scale3(lv, rcp_rn_nb(dist));
         const float datt = attenuation(dist, 50.0f);
         const f3 sd = normalize3(sdir);
         const float cosAngle = dot3({-L.x, -L.y, -L.z}, sd);                // CalculateSpotAttenuation :77-81
-        const float satt = saturatef((cosAngle - outerCos) / (innerCos - outerCos));
+        const float satt = saturatef(div_rn_nb(cosAngle - outerCos, innerCos - outerCos));
+        if (__ballot(datt * satt > 0.0f) == 0ull) continue;                  // outside the cone or the range: exact zeros, as above
         const f3 lc = scale3(scale3(scale3(color, intensity), datt), satt);
         lighting = add3(lighting, blinn_phong(L, V, N, lc, albedo, shininess));
     }
