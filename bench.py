@@ -284,9 +284,15 @@ def main():
         for _ in range(fps):
             frame()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    if args.profile_pass_only:
+        for _ in range(8):                    # (every dispatch of this process is then an isolated one: what rocprofv3 averages)
+            rig.slots[0].render()
+            dev.wait_idle()
+    else:
+        for _ in range(args.warmup):
+            step()
+    dev.wait_idle()                           # also reports (and acts on) the device status of the warm-up frames: a bin pool that
+    barrier()                                 # turned out too small is grown before the timed region, not inside it
     t0 = time.perf_counter()
     for _ in range(0 if args.profile_pass_only else args.steps):
         step()
@@ -313,15 +319,19 @@ def main():
     dev.set_profiling(m.Profile.TIMING)
     for _ in range(prof_frames):
         rig.slots[0].render()
+        if args.profile_pass_only:
+            dev.wait_idle()                   # (under a tracer / counter collection: strictly one frame on the GPU at a time)
     dev.wait_idle()
     iso = {name: dev.kernel_time(k) for k, name in enumerate(m.Kernel.NAMES)}
     iso_tl = summarize_timeline(dev.timeline(), m.Kernel.NAMES)
     # (b) the timed region's conditions: all lanes in flight (no band exchange: kernels only)
     dev.reset_kernel_times()
-    for _ in range(prof_frames):
-        rig.slots[rig.next_slot()].render()
-    dev.wait_idle()
-    flight_tl_raw = dev.timeline()
+    flight_tl_raw = []
+    if not args.profile_pass_only:
+        for _ in range(prof_frames):
+            rig.slots[rig.next_slot()].render()
+        dev.wait_idle()
+        flight_tl_raw = dev.timeline()
     flight_tl = summarize_timeline(flight_tl_raw, m.Kernel.NAMES)
     dev.set_profiling(0)
     if args.timeline_out and rank == 0:
@@ -329,12 +339,13 @@ def main():
             json.dump({"kernels": m.Kernel.NAMES, "frames_in_flight": nfif, "dispatches": flight_tl_raw}, f)
     # (c) fragment statistics: never part of a timed frame
     dev.reset_kernel_times()
-    dev.set_profiling(m.Profile.FRAGMENTS)
-    for _ in range(2):
-        rig.slots[0].render()
-    dev.set_profiling(0)
-    shaded, covered, scopes = dev.fragment_stats()
-    stat_frames = 2
+    shaded, covered, stat_frames = 0, 0, 2
+    if not args.profile_pass_only:
+        dev.set_profiling(m.Profile.FRAGMENTS)
+        for _ in range(stat_frames):
+            rig.slots[0].render()
+        dev.set_profiling(0)
+        shaded, covered, _scopes = dev.fragment_stats()
     dev.reset_kernel_times()
     stats = dev.stats()
 
@@ -385,7 +396,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wname}: {desc}", "triangles": tris, "width": scene.width, "height": scene.height,
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
-                       "parallelism": (f"tile-row split x{world} + RCCL band exchange ({args.gather}/{args.gather_algo})" if split
+                       "parallelism": (f"tile-row split x{world} + band exchange ({'RCCL through the C ABI, ' + args.gather_algo if comm is not None else 'torch.distributed ' + args.backend})" if split
                                        else (f"afr{world}" if world > 1 else "single")),
                        "frames_per_step": fps, "frames_in_flight": nfif},
             "timed_region_s": round(dt, 6), "us_per_frame": round(1e6 * dt / max(1, args.steps * fps), 4),

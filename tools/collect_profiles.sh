@@ -1,19 +1,27 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence behind bench.py's C2 line into gpurun_out/prof_<tag>/ (run on the GPU box):
-#   kernel-trace --stats of the isolated timing pass, three separate PMC passes (SQ instruction counters, FETCH_SIZE,
-#   WRITE_SIZE), the default bench line, and the other workloads' bench lines.  tools/make_profile_summaries.py turns
-#   the raw CSVs into the files committed under profiles/.
+# Collects the rocprofv3 evidence behind bench.py's lines into gpurun_out/prof_<tag>/ (run on the GPU box):
+#   stats/      rocprofv3 --kernel-trace --stats of the isolated pass (bench.py --profile-pass-only: one frame on the GPU at a time,
+#               every dispatch of the process isolated) -- the tracer's average durations must agree with roofline.avg_kernel_us
+#   pmc_*       separate PMC passes of the same command: SQ instruction mix, FETCH_SIZE, WRITE_SIZE (never combined with a trace domain
+#               other than --kernel-trace)
+#   trace/      rocprofv3 --kernel-trace of the driver's command (4 queue lanes in flight): per-dispatch begin / end
+#   bench_*     plain bench lines (no tool attached): the driver's command, and the other BASELINE configs
+# tools/make_profile_summaries.py <tag> turns the raw CSVs into the files committed under profiles/.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --profile-pass-only --steps 1000 --warmup 20 > $out/bench_profile_pass.json 2> $out/stats.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/pmc_sq -- python3 bench.py --profile-pass-only --steps 50 --warmup 5 > /dev/null 2> $out/pmc_sq.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --profile-pass-only --steps 50 --warmup 5 > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --profile-pass-only --steps 50 --warmup 5 > /dev/null 2> $out/pmc_write.err
-python3 bench.py --steps 3000 --warmup 100 > $out/bench_default.json 2> $out/bench_default.err
-for w in c3 c4 c5; do python3 bench.py --workload $w --steps 500 --no-cpu-baseline > $out/bench_$w.json 2>/dev/null; done
-find $out -name "*.csv" | head -20
-tail -c 600 $out/bench_default.json
+for w in c2 c3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > $out/bench_profile_pass_$w.json 2> $out/stats_$w.err
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/pmc_sq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_sq_$w.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_$w.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_write_$w.err
+  echo "collected $w"
+done
+rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --timeline-out $out/timeline_in_flight.json > $out/bench_default.json 2> $out/bench_default.err
+for w in c3 c4 c5; do python3 bench.py --workload $w --cpu-seconds 8 > $out/bench_$w.json 2>/dev/null; echo "bench $w done"; done
+find $out -name "*.csv" | head -30
+tail -c 400 $out/bench_default.json

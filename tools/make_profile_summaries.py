@@ -1,24 +1,30 @@
 """Turns gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the per-round files under profiles/.
 usage: make_profile_summaries.py <tag>"""
 import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
+
 
 def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit("missing " + pattern)
-    return max(hits, key=os.path.getmtime)      # gpurun merges into gpurun_out/: earlier runs' files may still be there
+    return max(hits, key=os.path.getmtime)
 
-shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_c2_rocprofv3_kernel_stats.csv"))
-for name in ("bench_profile_pass", "bench_default"):
-    line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
-    json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_c2_{name}.json"), "w"), indent=1)
-for w in ("c3", "c4", "c5"):
-    line = [l for l in open(os.path.join(src, f"bench_{w}.json")) if l.startswith("{")][-1]
-    json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{w}_bench.json"), "w"), indent=1)
+
+def last_json(path):
+    lines = [l for l in open(path) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def short(kern):
+    for k in ("raster_kernel", "geometry_kernel", "vertex_kernel", "fragment_count_kernel", "winner_count_kernel", "ordered_kernel"):
+        if k in kern:
+            return k
+    return None
+
 
 def means(pass_dir):
     acc = collections.defaultdict(list)
@@ -26,29 +32,96 @@ def means(pass_dir):
         acc[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
+
+for w in ("c2", "c3"):
+    shutil.copy(one(f"stats_{w}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{w}_rocprofv3_kernel_stats.csv"))
+    line = last_json(os.path.join(src, f"bench_profile_pass_{w}.json"))
+    json.dump(line, open(os.path.join(dst, f"{tag}_{w}_bench_profile_pass.json"), "w"), indent=1)
+    rows, per_kernel = [], collections.defaultdict(dict)
+    for pass_dir in (f"pmc_sq_{w}", f"pmc_fetch_{w}", f"pmc_write_{w}"):
+        for (kern, ctr), (n, mean) in sorted(means(pass_dir).items()):
+            if "mirhi::" not in kern:
+                continue
+            rows.append((pass_dir, kern, ctr, n, round(mean, 1)))
+            if short(kern):
+                per_kernel[short(kern)][ctr] = mean
+    with open(os.path.join(dst, f"{tag}_{w}_rocprofv3_pmc_summary.csv"), "w") as f:
+        cw = csv.writer(f)
+        cw.writerow(["pass", "kernel", "counter", "launches", "mean_per_launch"])
+        cw.writerows(rows)
+    traffic = {"workload": w, "kernel_source_sha16": line["roofline"]["kernel_source_sha16"],
+               "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --workload {w} --profile-pass-only",
+               "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide "
+                            "coalesced streams (MI355X_MICROARCH.md, HBM section), so the read side is doubled; that correction is calibrated "
+                            "for 16 B/lane streaming reads and is an upper bound for the record gathers here",
+               "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"]}
+    frame = 0
+    for k, d in per_kernel.items():
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            b = int(round((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024))
+            traffic[k] = {"fetch_size_kb": round(d["FETCH_SIZE"], 2), "write_size_kb": round(d["WRITE_SIZE"], 2), "hbm_bytes_per_launch": b}
+            frame += b
+    traffic["frame_hbm_bytes"] = frame
+    traffic["frame_over_algorithmic"] = round(frame / traffic["algorithmic_bytes"], 3)
+    json.dump(traffic, open(os.path.join(dst, f"{tag}_{w}_hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+
+json.dump(last_json(os.path.join(src, "bench_default.json")), open(os.path.join(dst, f"{tag}_c2_bench_default.json"), "w"), indent=1)
+for w in ("c3", "c4", "c5"):
+    j = last_json(os.path.join(src, f"bench_{w}.json"))
+    if j:
+        json.dump(j, open(os.path.join(dst, f"{tag}_{w}_bench.json"), "w"), indent=1)
+
+# ---- the 4-lane timed region as the tracer sees it: overlap of consecutive raster kernels, geometry -> raster gaps ----------
+trace = one("trace/**/*kernel_trace.csv")
 rows = []
-per_kernel = collections.defaultdict(dict)
-for pass_dir in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    for (kern, ctr), (n, mean) in sorted(means(pass_dir).items()):
-        if "mirhi::" not in kern:
-            continue
-        rows.append((pass_dir, kern, ctr, n, round(mean, 1)))
-        short = "raster_kernel" if "raster_kernel" in kern else ("geometry_kernel" if "geometry_kernel" in kern else "vertex_kernel")
-        per_kernel[short][ctr] = mean
-with open(os.path.join(dst, f"{tag}_c2_rocprofv3_pmc_summary.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["pass", "kernel", "counter", "launches", "mean_per_launch"])
-    w.writerows(rows)
-traffic = {"workload": "c2",
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --profile-pass-only --steps 50",
-           "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide "
-                        "coalesced streams (MI355X_MICROARCH.md, HBM section), so the read side is doubled; that correction is calibrated "
-                        "for 16 B/lane streaming reads and is an upper bound for the 48-B record gathers here"}
-for k, d in per_kernel.items():
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        traffic[k] = {"fetch_size_kb": d["FETCH_SIZE"], "write_size_kb": d["WRITE_SIZE"],
-                      "hbm_bytes_per_launch": int(round((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024))}
-json.dump(traffic, open(os.path.join(dst, f"{tag}_c2_hbm_traffic.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
-for r in rows:
-    print(*r)
+for r in csv.DictReader(open(trace)):
+    k = short(r["Kernel_Name"])
+    if k in ("raster_kernel", "geometry_kernel"):
+        rows.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
+rows.sort(key=lambda x: x[1])
+t0 = rows[0][1]
+ras = [x for x in rows if x[0] == "raster_kernel"]
+geo = [x for x in rows if x[0] == "geometry_kernel"]
+# steady state: the middle half of the trace
+lo, hi = len(ras) // 4, 3 * len(ras) // 4
+mid = ras[lo:hi]
+period = (mid[-1][2] - mid[0][2]) / (len(mid) - 1) / 1e3
+overlap = sum(max(0, min(mid[i][2], mid[i + 1][2]) - mid[i + 1][1]) for i in range(len(mid) - 1)) / (len(mid) - 1) / 1e3
+dur_r = sum(x[2] - x[1] for x in mid) / len(mid) / 1e3
+gmid = [x for x in geo if mid[0][1] <= x[1] <= mid[-1][1]]
+dur_g = sum(x[2] - x[1] for x in gmid) / max(1, len(gmid)) / 1e3
+# union of raster-busy time / wall time in the window
+busy, cur_b, cur_e = 0, None, None
+for _, b, e, _q in mid:
+    if cur_e is None or b > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_b
+        cur_b, cur_e = b, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_b
+wall = mid[-1][2] - mid[0][1]
+queues = sorted(set(x[3] for x in rows))
+summary = {
+    "command": "rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline (C2, 4 queue lanes, 512 frames per step)",
+    "raster_dispatches": len(ras), "geometry_dispatches": len(geo), "hardware_queues_seen": queues,
+    "window": f"raster dispatches {lo}..{hi} of {len(ras)} (steady state)",
+    "raster_us": round(dur_r, 3), "geometry_us": round(dur_g, 3),
+    "frame_period_us": round(period, 3), "raster_overlap_with_next_us": round(overlap, 3),
+    "raster_busy_fraction_of_wall": round(busy / wall, 4),
+    "traced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_traced.json")) or {}).get("value"),
+    "untraced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_default.json")) or {}).get("value"),
+}
+json.dump(summary, open(os.path.join(dst, f"{tag}_c2_timed_region_trace_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
+with open(os.path.join(dst, f"{tag}_c2_timed_region_trace_excerpt.csv"), "w") as f:
+    cw = csv.writer(f)
+    cw.writerow(["kernel", "begin_us", "end_us", "queue"])
+    for k, b, e, q in [x for x in rows if mid[0][1] <= x[1]][:64]:
+        cw.writerow([k, round((b - t0) / 1e3, 3), round((e - t0) / 1e3, 3), q])
+tl = os.path.join(src, "timeline_in_flight.json")
+if os.path.exists(tl):
+    j = json.load(open(tl))
+    j["dispatches"] = j["dispatches"][:256]
+    json.dump(j, open(os.path.join(dst, f"{tag}_c2_timeline_in_flight_excerpt.json"), "w"))
