@@ -252,6 +252,9 @@ typedef enum { MIRHI_KERNEL_GEOMETRY = 0, MIRHI_KERNEL_RASTER = 1, MIRHI_KERNEL_
  *   MIRHI_PROFILE_FRAGMENTS  fragment statistics (below): one extra counting kernel per scope and a few instructions in the
  *                            resolve -- never combine with a throughput measurement */
 enum { MIRHI_PROFILE_TIMING = 1, MIRHI_PROFILE_FRAGMENTS = 2 };
+/* MIRHI_PROFILE_TIMING | MIRHI_PROFILE_ONE_LANE(k): only the dispatches of queue lane k are timed; the other lanes run as in an
+ * untimed frame loop (a timed dispatch is completed through its own signal and overlaps its neighbours less than an untimed one) */
+#define MIRHI_PROFILE_ONE_LANE(k) ((((uint32_t)(k) + 1u) & 0xFFu) << 8)
 mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable);
 /* accumulated since the last reset; waits for outstanding dispatches */
 mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches);

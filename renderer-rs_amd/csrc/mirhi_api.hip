@@ -1384,7 +1384,11 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             // as "no coverage" -- an all-zero record is a degenerate triangle whose edge functions are negative everywhere
             if (P.ordered_recs && P.ordered_count) HIP_TRY(hipMemsetAsync(P.ordered_recs, 0, (size_t)P.ordered_count * sizeof(TriRec), stream));
             LaunchTiming tv{}, tg{}, tc{}, tr{};
-            const bool timed = (dev->profiling & MIRHI_PROFILE_TIMING) != 0, counted = (dev->profiling & MIRHI_PROFILE_FRAGMENTS) != 0;
+            // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
+            // untimed: a timed dispatch completes through its own signal and does not overlap its neighbours the way an untimed one does)
+            const uint32_t only_lane = (dev->profiling >> 8) & 0xFFu;
+            const bool timed = (dev->profiling & MIRHI_PROFILE_TIMING) != 0 && (only_lane == 0u || only_lane - 1u == c->lane);
+            const bool counted = (dev->profiling & MIRHI_PROFILE_FRAGMENTS) != 0;
             if (timed) {
                 mirhi_result r;
                 if (P.vs_total_slots && (r = timing_begin(dev, MIRHI_KERNEL_VERTEX, c->lane, &tv)) != MIRHI_OK) return r;
@@ -1553,7 +1557,7 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
 extern "C" mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable) {
     NULL_CHECK(dev, "device");
     std::lock_guard<std::mutex> lock(dev->mu);
-    dev->profiling = enable & (MIRHI_PROFILE_TIMING | MIRHI_PROFILE_FRAGMENTS);
+    dev->profiling = enable & (MIRHI_PROFILE_TIMING | MIRHI_PROFILE_FRAGMENTS | 0xFF00u);
     return MIRHI_OK;
 }
 // Reads the timed dispatches back: duration = elapsed(start, stop) of the dispatch's own pair; position on the timeline =

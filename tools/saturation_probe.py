@@ -57,5 +57,5 @@ def run(T, L):
 
 
 print(json.dumps({"workload": workload, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}))
-for T, L in ((1, 2), (1, 4), (1, 4), (1, 6), (1, 8), (2, 2), (2, 4), (4, 2), (1, 4)):
+for T, L in ((1, 2), (1, 3), (1, 4), (1, 4), (1, 6), (1, 8), (1, 8), (2, 4), (1, 4)):
     print(json.dumps(run(T, L)), flush=True)
