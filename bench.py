@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames (own command buffer + target) overlapped on the GPU; the reference keeps 2 "
                          "(MAX_FRAMES_IN_FLIGHT) + 1 swapchain image")
+    ap.add_argument("--frames-per-submit", type=int, default=1,
+                    help="command buffers handed to one mirhi_queue_submit call (vkQueueSubmit with several command buffers): frames of "
+                         "equal shape then share one batch of kernel launches; frames in flight = this x --frames-in-flight")
     ap.add_argument("--profile-pass-only", action="store_true",
                     help="skip the timed region: only the per-dispatch timing passes (the command profiled with rocprofv3 --pmc)")
     ap.add_argument("--timeline-out", default=None, help="write the per-dispatch timeline of the in-flight pass to this JSON file")
@@ -223,23 +226,32 @@ def main():
     class Rig:
         """A device with `lanes` frames in flight: one colour target + command buffer per frame (swapchain images)."""
 
-        def __init__(self, lanes, band=None, rows=None):
+        def __init__(self, lanes, band=None, rows=None, per_submit=1):
             self.dev = m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
             self.dev.set_queue_lanes(lanes)
             if band is not None:
                 self.dev.set_tile_split(*band)
             wrap = make_wrap()
-            self.frames, self.slots, self.counter = [], [], 0
-            for _ in range(lanes):
+            self.frames, self.slots, self.counter, self.per_submit = [], [], 0, per_submit
+            for i in range(lanes * per_submit):
                 frame = torch.zeros((rows or scene.height, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
                 target = m.Image(self.dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
                 self.frames.append(frame)
                 self.slots.append(m.SceneResources(self.dev, scene, fmt, color_image=target, wrap_buffers=wrap))
+                self.slots[-1].cmd.set_queue_lane((i // per_submit) % lanes)      # group g = slots [g * per_submit, ...) on lane g
+            self.groups = [self.slots[g * per_submit:(g + 1) * per_submit] for g in range(lanes)]
 
         def next_slot(self):
             i = self.counter % len(self.slots)
             self.counter += 1
             return i
+
+        def submit_group(self):
+            """per_submit frames in one mirhi_queue_submit call; returns the slots rendered"""
+            g = self.groups[(self.counter // self.per_submit) % len(self.groups)]
+            self.counter += self.per_submit
+            self.dev.submit([sl.cmd for sl in g])
+            return g
 
         def destroy(self, comm=None):
             self.dev.wait_idle()
@@ -252,12 +264,15 @@ def main():
             self.dev.destroy()
 
     nfif = max(1, min(8, args.frames_in_flight))
+    per_submit = max(1, min(8, args.frames_per_submit))
+    if fps % per_submit:
+        fps = (fps // per_submit + 1) * per_submit
     if split:
         nfif = min(nfif, 2)
         rows = multigpu.padded_rows(scene.height, world) if not use_abi_gather else scene.height
-        rig = Rig(nfif, band=(rank, world), rows=rows)
+        rig = Rig(nfif, band=(rank, world), rows=rows, per_submit=per_submit)
     else:
-        rig = Rig(nfif)
+        rig = Rig(nfif, per_submit=per_submit)
     dev = rig.dev
 
     comm, rccl_ranks = None, world
@@ -271,18 +286,18 @@ def main():
         rccl_ranks = comm.world()
     algo = m.GatherAlgo.DIRECT if args.gather_algo == "direct" else m.GatherAlgo.BROADCAST
 
-    def frame():
-        i = rig.next_slot()
-        rig.slots[i].render()
-        if split:
-            if comm is not None:
-                comm.all_gather_bands(rig.slots[i].color, rig.slots[i].cmd, algo)
-            else:
-                multigpu.all_gather_bands(rig.frames[i], rank, world, via_host=(args.backend == "gloo"))
+    def frames():
+        """per_submit frames: one submit call, then (split) the band exchange of each"""
+        for sl in rig.submit_group():
+            if split:
+                if comm is not None:
+                    comm.all_gather_bands(sl.color, sl.cmd, algo)
+                else:
+                    multigpu.all_gather_bands(rig.frames[rig.slots.index(sl)], rank, world, via_host=(args.backend == "gloo"))
 
     def step():
-        for _ in range(fps):
-            frame()
+        for _ in range(fps // per_submit):
+            frames()
 
     if args.profile_pass_only:
         for _ in range(8):                    # (every dispatch of this process is then an isolated one: what rocprofv3 averages)
@@ -398,7 +413,7 @@ def main():
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
                        "parallelism": (f"tile-row split x{world} + band exchange ({'RCCL through the C ABI, ' + args.gather_algo if comm is not None else 'torch.distributed ' + args.backend})" if split
                                        else (f"afr{world}" if world > 1 else "single")),
-                       "frames_per_step": fps, "frames_in_flight": nfif},
+                       "frames_per_step": fps, "frames_in_flight": nfif * per_submit, "queue_lanes": nfif, "frames_per_submit": per_submit},
             "timed_region_s": round(dt, 6), "us_per_frame": round(1e6 * dt / max(1, args.steps * fps), 4),
             "shaded_mpix_per_s": round(shaded_per_frame * frames_total / dt / 1e6, 1),
             "overdraw": round(covered / shaded, 4) if shaded else None,

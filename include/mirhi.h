@@ -218,6 +218,11 @@ typedef enum { MIRHI_TEXTURE_ALBEDO = 0 /* t0 */, MIRHI_TEXTURE_NORMAL = 1 /* t1
 
 mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out);                 /* CommandPool::new + CommandBuffer::new :89,:297 */
 mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd);
+/* Queue lane (mirhi_device_set_queue_lanes) this command buffer is submitted on; by default command buffers take the lanes round
+ * robin in creation order.  A submit of several command buffers that are each one plain rendering scope of the same shape (the
+ * frames of a frame loop) runs as ONE batch of launches on the first one's lane (vkQueueSubmit with several command buffers,
+ * renderer.rs:407-424: no ordering between them is promised without a barrier). */
+mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane);
 mirhi_result mirhi_cmd_begin(mirhi_cmd* cmd);                                       /* begin :333 (ONE_TIME_SUBMIT) */
 mirhi_result mirhi_cmd_begin_reusable(mirhi_cmd* cmd);                              /* begin_reusable :353 */
 mirhi_result mirhi_cmd_end(mirhi_cmd* cmd);                                         /* end :372 */

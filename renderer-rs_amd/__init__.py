@@ -205,6 +205,7 @@ _SIGNATURES = {
     "mirhi_rendering_info_default": (None, [C.POINTER(RenderingInfo)]),
     "mirhi_cmd_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirhi_cmd_destroy": (C.c_int32, [C.c_void_p]),
+    "mirhi_cmd_set_queue_lane": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_cmd_begin": (C.c_int32, [C.c_void_p]),
     "mirhi_cmd_begin_reusable": (C.c_int32, [C.c_void_p]),
     "mirhi_cmd_end": (C.c_int32, [C.c_void_p]),
@@ -604,6 +605,9 @@ class CommandBuffer:
     def set_scissor(self, x, y, width, height):
         sc = Rect2D(x, y, width, height)
         check(lib().mirhi_cmd_set_scissor(self.handle, C.byref(sc)))
+
+    def set_queue_lane(self, lane: int):
+        check(lib().mirhi_cmd_set_queue_lane(self.handle, lane))
 
     def draw(self, vertex_count, instance_count=1, first_vertex=0, first_instance=0):
         check(lib().mirhi_cmd_draw(self.handle, vertex_count, instance_count, first_vertex, first_instance))

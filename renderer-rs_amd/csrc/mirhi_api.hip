@@ -182,6 +182,7 @@ struct mirhi_cmd {
     mirhi_device* dev;
     CmdState state = CMD_INITIAL;
     uint32_t lane = 0;                     // submit stream of this command buffer (frames in flight overlap across lanes)
+    hipStream_t last_stream = nullptr;     // the stream its last submission ran on (a batched submit runs on the first command buffer's lane)
     bool one_time = true;
     bool in_rendering = false;
     std::vector<RecordedPass> passes;
@@ -708,6 +709,14 @@ extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
     *out = c;
     return MIRHI_OK;
 }
+extern "C" mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane) {
+    NULL_CHECK(cmd, "command buffer");
+    if (lane >= cmd->dev->lanes.size()) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lane %u of %zu", lane, cmd->dev->lanes.size());
+    if (cmd->last_stream) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
+    HIP_TRY(hipStreamSynchronize(cmd->dev->lanes[cmd->lane < cmd->dev->lanes.size() ? cmd->lane : 0]));
+    cmd->lane = lane;
+    return MIRHI_OK;
+}
 extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
     (void)sync_all_lanes(cmd->dev);
@@ -1066,6 +1075,12 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     if (cmd->lane >= dev->lanes.size()) cmd->lane = 0;
     hipStream_t stream = dev->lanes[cmd->lane];
     HIP_TRY(hipStreamSynchronize(stream));
+    if (cmd->last_stream && cmd->last_stream != stream) {
+        bool live = false;
+        for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
+        if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
+        cmd->last_stream = nullptr;
+    }
     size_t total_draws = 0, max_tiles = 0, max_pages = 0, max_big = 0;
     struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };
     std::vector<Geo> geo;
@@ -1370,9 +1385,41 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             if (rp != MIRHI_OK) return rp;
         }
     std::lock_guard<std::mutex> lock(dev->mu);
-    for (uint32_t i = 0; i < cmd_count; i++) {
+    // Batched form: the command buffers of one submit, when each is one plain rendering scope of the same shape and kernel variants
+    // (the frames of a frame loop), share one vertex, one geometry and one raster launch on the first one's queue lane -- the
+    // ramp-up and drain of a kernel and the latency chain of the geometry kernel are paid once per batch, not once per frame.
+    bool batched = cmd_count >= 2 && cmd_count <= (uint32_t)MAX_BATCH && dev->profiling == 0 && !getenv("MIRHI_NO_BATCH");
+    for (uint32_t i = 0; batched && i < cmd_count; i++) {
+        const mirhi_cmd* c = cmds[i];
+        batched = c->plan.size() == 1 && raster_batchable(c->plan[0]) &&
+                  raster_variant_key(c->plan[0], c->plan_programs[0]) == raster_variant_key(cmds[0]->plan[0], cmds[0]->plan_programs[0]) &&
+                  c->plan_programs[0] == cmds[0]->plan_programs[0];
+        for (uint32_t j = 0; batched && j < i; j++) batched = cmds[j] != c;          // (the same command buffer twice: one after the other)
+    }
+    if (batched) {
+        hipStream_t stream = dev->lanes[cmds[0]->lane < dev->lanes.size() ? cmds[0]->lane : 0];
+        const PassParams* P[MAX_BATCH]; const PassParams* dp[MAX_BATCH]; uint32_t* big[MAX_BATCH];
+        for (uint32_t i = 0; i < cmd_count; i++) {
+            mirhi_cmd* c = cmds[i];
+            if (c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
+            c->last_stream = stream;
+            if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
+            P[i] = &c->plan[0];
+            dp[i] = c->ws.params + c->ws.parity;
+            big[i] = c->ws.big_counts + c->ws.parity;
+            c->ws.parity ^= 1u;
+            dev->stats.frames_submitted++;
+            dev->stats.triangles_submitted += c->plan[0].total_tris;
+        }
+        HIP_TRY(launch_vertex_batch(P, dp, cmd_count, stream));
+        HIP_TRY(launch_geometry_batch(P, dp, cmd_count, stream));
+        HIP_TRY(launch_raster_batch(P, dp, big, cmd_count, cmds[0]->plan_programs[0], stream));
+    }
+    for (uint32_t i = 0; !batched && i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
+        if (c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
+        c->last_stream = stream;
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
             const PassParams& P = c->plan[pi];
@@ -1424,9 +1471,9 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     if (fence) {
         if (!fence->event) HIP_TRY(hipEventCreateWithFlags(&fence->event, hipEventDisableTiming));
         // the fence follows the last command buffer's lane and waits for the other lanes used by this submit
-        hipStream_t fstream = cmd_count ? dev->lanes[cmds[cmd_count - 1]->lane < dev->lanes.size() ? cmds[cmd_count - 1]->lane : 0] : dev->stream;
+        hipStream_t fstream = cmd_count ? cmds[cmd_count - 1]->last_stream : dev->stream;
         for (uint32_t i = 0; i + 1 < cmd_count; i++) {
-            hipStream_t other = dev->lanes[cmds[i]->lane < dev->lanes.size() ? cmds[i]->lane : 0];
+            hipStream_t other = cmds[i]->last_stream;
             if (other != fstream) {
                 if (!fence->join) HIP_TRY(hipEventCreateWithFlags(&fence->join, hipEventDisableTiming));
                 HIP_TRY(hipEventRecord(fence->join, other));
@@ -1746,7 +1793,7 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
     if (dev->split_world != comm->world || dev->split_rank != comm->rank)
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
     HIP_TRY(hipSetDevice(dev->ordinal));
-    hipStream_t lane = dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
+    hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
     hipStream_t stream = comm->stream;
     const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;
     const size_t row_bytes = (size_t)frame->width * format_bpp(frame->format);

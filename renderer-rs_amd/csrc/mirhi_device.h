@@ -174,4 +174,10 @@ struct RasterHead {
     uint32_t fixed_recs;              // PassParams::fixed_recs
 };
 
+// A batched launch: the independent rendering scopes of one mirhi_queue_submit (equal target shape, equal raster variant) share
+// one vertex, one geometry and one raster launch; their arguments travel by value in the kernarg segment.
+constexpr int MAX_BATCH = 8;
+struct GeometryBatch { const PassParams* params[MAX_BATCH]; GeometryHead head[MAX_BATCH]; uint32_t blocks[MAX_BATCH]; };
+struct RasterBatch { const PassParams* params[MAX_BATCH]; RasterHead head[MAX_BATCH]; };
+
 }  // namespace mirhi

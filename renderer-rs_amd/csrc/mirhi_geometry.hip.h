@@ -213,9 +213,10 @@ __device__ __forceinline__ uint32_t find_draw(ParamsRef P, uint32_t prim) {
 // ------------------------------------------------------------------------------------------------
 // a4: vertex-shader pre-pass for the MODEL / MODEL_FULL programs (vertex/model.hlsl:39-68)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* __restrict__ params) {
+__device__ __forceinline__ void vertex_body(const PassParams* __restrict__ params) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    if (slot0 >= P.vs_total_slots) return;              // (batched launch: the grid is sized for the largest scope)
     const MIRHI_CONST VsJob* jobs = (const MIRHI_CONST VsJob*)(uintptr_t)P.vs_jobs;
     uint32_t lo = 0, hi = P.num_vs_jobs;
     while (hi - lo > 1) {
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* 
         out[4] = make_uint4(__float_as_uint(B.y), __float_as_uint(B.z), 0u, 0u);
     }
 }
+
+__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel(const PassParams* __restrict__ params) { vertex_body(params); }
+__global__ __launch_bounds__(GEOM_THREADS) void vertex_kernel_batch(const GeometryBatch B) { vertex_body(B.params[blockIdx.y]); }
 
 __device__ __forceinline__ uint32_t pack_bgra8_srgb(f4 c);
 
@@ -471,7 +475,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
 // chip several times over (C4 geometry 61.4 -> 57.4 us); 5 (up to 102) for small scopes, where a wave is alone on its SIMD
 // and only the length of its dependent instruction stream counts (C2: 7.4 us against 8.2 with the tighter allocation).
 template <int WAVES>
-__global__ __launch_bounds__(GEOM_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
+__device__ __forceinline__ void geometry_body(const PassParams* __restrict__ params, const GeometryHead& H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     // 5.4 KB of LDS per one-wave workgroup: 30 fit a CU, which is what lets 7 waves per SIMD be resident (at 7.9 KB the LDS
     // capped the kernel at 5).  The clipper's polygon slots (2.5 KB: clipping lanes take turns, 8 at a time) reuse the
@@ -569,6 +573,19 @@ __global__ __launch_bounds__(GEOM_THREADS) __attribute__((amdgpu_waves_per_eu(WA
         todo &= ~__ballot(mine);
     }
     GSTAMP(3);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(GEOM_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void geometry_kernel(const PassParams* __restrict__ params, const GeometryHead H) {
+    geometry_body<WAVES>(params, H);
+}
+// the scopes of one batched submit (see raster_kernel_batch): grid (waves of the largest scope, scopes)
+template <int WAVES>
+__global__ __launch_bounds__(GEOM_THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void geometry_kernel_batch(const GeometryBatch B) {
+    const uint32_t y = blockIdx.y;
+    if (blockIdx.x >= B.blocks[y]) return;
+    const GeometryHead H = B.head[y];
+    geometry_body<WAVES>(B.params[y], H);
 }
 
 #endif  // MIRHI_GEOMETRY_HIP_H

@@ -104,6 +104,77 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     return hipGetLastError();
 }
 
+// ---- batched launches --------------------------------------------------------------------------------------------
+uint64_t raster_variant_key(const PassParams& P, uint32_t programs) {
+    const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
+    const uint32_t keyed = P.pred ? 2u : (plain ? 0u : 1u);
+    const uint32_t tp = (!P.pred && P.tp_max_area) ? 1u : 0u;
+    const uint32_t teams = (tp && P.raster_teams == 2u && (programs == 2 || programs >= 4)) ? 2u : 1u;
+    const uint32_t prog = programs >= 4 ? 4u : programs;
+    return (uint64_t)prog | ((uint64_t)keyed << 4) | ((uint64_t)tp << 8) | ((uint64_t)teams << 12) | ((uint64_t)(P.xcd_swizzle > 1u ? 1u : 0u) << 16) |
+           ((uint64_t)P.tiles_x << 20) | ((uint64_t)(P.tile_row_end - P.tile_row_begin) << 36) | ((uint64_t)(P.ordered_recs ? 1u : 0u) << 52);
+}
+
+hipError_t launch_vertex_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream) {
+    GeometryBatch B{};
+    uint32_t most = 0;
+    for (uint32_t i = 0; i < n; i++) { B.params[i] = dev_params[i]; most = P[i]->vs_total_slots > most ? P[i]->vs_total_slots : most; }
+    if (most == 0) return hipSuccess;
+    hipLaunchKernelGGL(vertex_kernel_batch, dim3(most / GEOM_THREADS, n), dim3(GEOM_THREADS), 0, stream, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream) {
+    GeometryBatch B{};
+    uint32_t most = 0, total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        B.params[i] = dev_params[i];
+        B.head[i] = GeometryHead{P[i]->draws, P[i]->num_draws};
+        B.blocks[i] = P[i]->total_slots / GEOM_THREADS;
+        most = B.blocks[i] > most ? B.blocks[i] : most; total += B.blocks[i];
+    }
+    if (most == 0) return hipSuccess;
+    if (total > 5u * 1024u) hipLaunchKernelGGL(geometry_kernel_batch<7>, dim3(most, n), dim3(GEOM_THREADS), 0, stream, B);
+    else hipLaunchKernelGGL(geometry_kernel_batch<5>, dim3(most, n), dim3(GEOM_THREADS), 0, stream, B);
+    return hipGetLastError();
+}
+
+template <int KEYED, int TP, int TEAMS = 1>
+static void launch_raster_batch_k(const RasterBatch& B, uint32_t programs, dim3 grid, hipStream_t stream) {
+    const dim3 block(RASTER_THREADS * TEAMS);
+    if (TEAMS > 1) {
+        if (programs == 2) hipLaunchKernelGGL((raster_kernel_batch<2, KEYED, TP, TEAMS>), grid, block, 0, stream, B);
+        else hipLaunchKernelGGL((raster_kernel_batch<4, KEYED, TP, TEAMS>), grid, block, 0, stream, B);
+        return;
+    }
+    if (programs == 2) hipLaunchKernelGGL((raster_kernel_batch<2, KEYED, TP>), grid, block, 0, stream, B);
+    else if (programs == 3) hipLaunchKernelGGL((raster_kernel_batch<3, KEYED, TP>), grid, block, 0, stream, B);
+    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel_batch<4, KEYED, TP>), grid, block, 0, stream, B);
+    else hipLaunchKernelGGL((raster_kernel_batch<1, KEYED, TP>), grid, block, 0, stream, B);
+}
+
+hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream) {
+    const PassParams& P = *Ps[0];
+    const uint32_t rows = P.tile_row_end - P.tile_row_begin;
+    if (rows == 0 || P.tiles_x == 0) return hipSuccess;
+    RasterBatch B{};
+    for (uint32_t i = 0; i < n; i++) {
+        const PassParams& Q = *Ps[i];
+        B.params[i] = dev_params[i];
+        B.head[i] = RasterHead{Q.bin_count, Q.bin_pool, big_count[i], Q.tiles_x, Q.tile_row_begin, Q.bin_cap, Q.big_cap, Q.sub_cap, Q.count_stride, Q.fixed_recs};
+    }
+    const dim3 grid(P.tiles_x, rows, n);           // (the XCD run-length order of a 1-D grid is a measurement knob: such scopes are not batched)
+    const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
+    // only the variants a frame loop meets are instantiated in batched form: LESS / LESS_OR_EQUAL keys, with and without the
+    // triangle-parallel path and the two-team mesh mode; everything else goes scope by scope (mirhi_queue_submit checks)
+    if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) launch_raster_batch_k<0, 1, 2>(B, programs, grid, stream);
+    else if (P.tp_max_area) launch_raster_batch_k<0, 1>(B, programs, grid, stream);
+    else launch_raster_batch_k<0, 0>(B, programs, grid, stream);
+    (void)plain;
+    return hipGetLastError();
+}
+bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs; }
+
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0 || P.ordered_recs) return hipSuccess;

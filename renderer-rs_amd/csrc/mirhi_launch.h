@@ -15,6 +15,13 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
 // programs: bit0 TRIANGLE, bit1 MODEL / MODEL_FULL, bit2 MODEL_PBR
 hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t = {});
+// Batched forms: n (2 .. MAX_BATCH) independent scopes of equal target shape and equal kernel variants (raster_variant_key) in one
+// launch each; P[i] / dev_params[i] / big_count[i] as above, per scope.  Ordered (blended) scopes are never batched.
+bool raster_batchable(const PassParams& P);                                 // a variant that exists in batched form
+uint64_t raster_variant_key(const PassParams& P, uint32_t programs);        // equal keys <=> the same raster_kernel instantiation and grid
+hipError_t launch_vertex_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream);
+hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream);
+hipError_t launch_raster_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream);
 // profiling only: counts the fragments the scope's binned triangles cover (before any depth test) into P.frag_stats[1];
 // runs between the geometry and the raster kernel (the raster kernel re-arms the bin counters)
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t = {});

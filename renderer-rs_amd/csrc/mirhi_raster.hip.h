@@ -473,7 +473,7 @@ template <int PROGS, int KEYED, int TP, int TEAMS = 1>
 #ifndef MIRHI_PROGS2_WAVES
 #define MIRHI_PROGS2_WAVES 5
 #endif
-__global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? MIRHI_PROGS2_WAVES : 4))) void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+__device__ __forceinline__ void raster_body(const PassParams* __restrict__ params, const RasterHead& H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     // mesh variants stage with all four waves: their small records are resolved while staging (triangle-parallel), so a
     // hot tile's serial chain is one pass per CHUNK records; the sparse variants keep 192 (LDS per workgroup bounds
@@ -770,6 +770,23 @@ __global__ __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) 
         }
     }
     STAMP(4);
+}
+
+#define MIRHI_RASTER_BOUNDS __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? MIRHI_PROGS2_WAVES : 4)))
+// one rendering scope: grid (tiles_x, tile rows of the band)
+template <int PROGS, int KEYED, int TP, int TEAMS = 1>
+__global__ MIRHI_RASTER_BOUNDS void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
+    raster_body<PROGS, KEYED, TP, TEAMS>(params, H);
+}
+// up to MAX_BATCH independent rendering scopes of equal shape (the frames of one mirhi_queue_submit): grid (tiles_x, tile rows, scopes).
+// One launch instead of one per frame: the ramp-up and drain of a kernel (5 us of the 11 us an isolated 10k-triangle raster kernel
+// takes) are paid once per batch, and the frames' tiles fill the chip back to back.  The per-scope arguments come by value in the
+// kernarg segment, indexed by blockIdx.z (scalar loads).
+template <int PROGS, int KEYED, int TP, int TEAMS = 1>
+__global__ MIRHI_RASTER_BOUNDS void raster_kernel_batch(const RasterBatch B) {
+    const uint32_t z = blockIdx.z;
+    const RasterHead H = B.head[z];
+    raster_body<PROGS, KEYED, TP, TEAMS>(B.params[z], H);
 }
 
 #endif  // MIRHI_RASTER_HIP_H
