@@ -63,7 +63,7 @@ def parse_args():
                     help="skip the timed region: only the per-dispatch timing passes (the command profiled with rocprofv3 --pmc)")
     ap.add_argument("--timeline-out", default=None, help="write the per-dispatch timeline of the in-flight pass to this JSON file")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only for rehearsals of N > 1 on a one-GPU box")
-    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the secondary measurements (one-GPU reference, AFR)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (N = 1: batched submits; N > 1: one-GPU reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     return ap.parse_args()
@@ -365,6 +365,26 @@ def main():
     stats = dev.stats()
 
     extras = {}
+    if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
+        # the same frame loop with 8 command buffers per mirhi_queue_submit call (vkQueueSubmit with several command buffers): the
+        # frames of a call share one batch of launches.  Reported beside the headline, which keeps one frame per submit.
+        try:
+            br = Rig(nfif, per_submit=8)
+            for _ in range(max(8, fps // 8 // 4)):
+                br.submit_group()
+            br.dev.wait_idle()
+            nb = max(16, 4 * fps // 8)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nb):
+                br.submit_group()
+            br.dev.wait_idle()
+            d1 = time.perf_counter() - t1
+            extras["batched_submit"] = {"value": round(tris * nb * 8 / d1 / 1e6, 3), "unit": "Mtris/s", "frames_per_submit": 8, "queue_lanes": nfif,
+                                        "frames": nb * 8, "us_per_frame": round(1e6 * d1 / (nb * 8), 4)}
+            br.destroy()
+        except Exception as e:
+            extras["batched_submit"] = {"error": repr(e)}
     if world > 1 and not args.no_extras and not args.profile_pass_only:
         try:
             # the same workload, whole frame on ONE GPU (every rank renders its own copy: no exchange): the N = 1 point of the curve
