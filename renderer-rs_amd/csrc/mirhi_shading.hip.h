@@ -112,7 +112,23 @@ __device__ __forceinline__ f4 sample_texture(DrawRef D, int slot, float u, float
 #pragma clang fp contract(off)
 // Everything that feeds pow(NdotH, shininess) must match the oracle bit for bit: an exponent of up to 2048
 // turns a 1-ulp difference in NdotH into a 1e-4 relative difference of the specular term.
-struct Varyings { f3 world, normal, tangent, bitangent; float u, v; };
+// Shaded vertices are interpolated as they are fetched: ((b0 * a0 + b1 * a1) + b2 * a2) accumulated vertex by vertex -- the oracle's
+// operation order -- so that one vertex's attributes are live at a time, not three (3 x 14 floats held 42 VGPRs and, together with
+// the exact IEEE sequences, pushed the MODEL variants past their 96 registers).
+__device__ __forceinline__ void acc1(float& a, float bk, float v, uint32_t k) { const float t = bk * v; a = k == 0u ? t : a + t; }
+__device__ __forceinline__ void acc3(f3& a, float bk, f3 v, uint32_t k) { acc1(a.x, bk, v.x, k); acc1(a.y, bk, v.y, k); acc1(a.z, bk, v.z, k); }
+// tangent and bitangent of the three shaded vertices (MODEL_FULL / MODEL_PBR layout, words 3 and 4), interpolated on demand: only
+// pixels under a real normal map need them
+__device__ __forceinline__ void interp_tangent_frame(DrawRef D, const uint32_t vi[3], const float b[3], f3& T, f3& Bt) {
+    T = {0.0f, 0.0f, 0.0f}; Bt = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words;
+        const uint4 w3 = sv[3], w4 = sv[4];
+        acc3(T, b[k], {__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z)}, k);
+        acc3(Bt, b[k], {__uint_as_float(w3.w), __uint_as_float(w4.x), __uint_as_float(w4.y)}, k);
+    }
+}
 
 __device__ __forceinline__ f3 interp3(const float b[3], f3 a0, f3 a1, f3 a2) {
     return {(b[0] * a0.x + b[1] * a1.x) + b[2] * a2.x, (b[0] * a0.y + b[1] * a1.y) + b[2] * a2.y,
@@ -198,10 +214,8 @@ __device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const Pb
 }
 
 // pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
-__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyings vv[3], f3 worldPos, f3 V, f3 N, const UvGrad& grad) {
+__device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const uint32_t vi[3], float u, float v, f3 worldPos, f3 V, f3 N, const UvGrad& grad) {
     const CBytePtr M = cb(D.material);                                                  // MaterialData :36-59 (80 B)
-    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
-    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
     f4 baseColor = {ldcf(M, 0), ldcf(M, 4), ldcf(M, 8), ldcf(M, 12)};
     float metallic = ldcf(M, 16), roughness = ldcf(M, 20), ao = ldcf(M, 24);
     const float normalScale = ldcf(M, 28);
@@ -224,8 +238,9 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
         const f3 ncm1 = {nc.x - 1.0f, nc.y - 1.0f, nc.z - 1.0f};
         if (!(length3(ncm1) < 0.01f)) {
             const f3 ns = normalize3({(nc.x * 2.0f - 1.0f) * normalScale, (nc.y * 2.0f - 1.0f) * normalScale, nc.z * 2.0f - 1.0f});
-            const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
-            const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+            f3 Ti, Bi;
+            interp_tangent_frame(D, vi, b, Ti, Bi);
+            const f3 T = normalize3(Ti), Bt = normalize3(Bi);
             N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
         }
     }
@@ -285,27 +300,30 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const Varyi
 // FULL: the variant that also carries the Cook-Torrance program and mip-mapped (trilinear) sampling
 template <bool FULL>
 __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
-    f4 c[3]; Varyings vv[3];
+    f4 c[3]; uint32_t vi[3];
     const bool full = D.program >= 2;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel
-        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)fetch_index(D, 3u * tri + k) * D.vs_words;
-        const uint4 w0 = sv[0], w1 = sv[1], w2 = sv[2];
+        // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel: the clip position first
+        vi[k] = fetch_index(D, 3u * tri + k);
+        const uint4 w0 = (reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words)[0];
         c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
-        vv[k].world = {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)};
-        vv[k].normal = {__uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y)};
-        if (full) {
-            const uint4 w3 = sv[3], w4 = sv[4];
-            vv[k].u = __uint_as_float(w2.z); vv[k].v = __uint_as_float(w2.w);
-            vv[k].tangent = {__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z)};
-            vv[k].bitangent = {__uint_as_float(w3.w), __uint_as_float(w4.x), __uint_as_float(w4.y)};
-        }
     }
     float b[3];
     barycentrics<false>(D, c, pxc, pyc, b);
-    const f3 worldPos = interp3(b, vv[0].world, vv[1].world, vv[2].world);
-    const f3 Nv = interp3(b, vv[0].normal, vv[1].normal, vv[2].normal);
+    f3 worldPos = {0.0f, 0.0f, 0.0f}, Nv = {0.0f, 0.0f, 0.0f};
+    float u = 0.0f, v = 0.0f, uvk[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words;
+        const uint4 w1 = sv[1], w2 = sv[2];
+        acc3(worldPos, b[k], {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)}, k);
+        acc3(Nv, b[k], {__uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y)}, k);
+        if (full) {
+            uvk[k][0] = __uint_as_float(w2.z); uvk[k][1] = __uint_as_float(w2.w);
+            acc1(u, b[k], uvk[k][0], k); acc1(v, b[k], uvk[k][1], k);
+        }
+    }
     const CFloatPtr cam = cf(D.camera);
     const f3 camPos = {cam[48], cam[49], cam[50]};          // cameraPosition @192 B
     const f3 V = normalize3(sub3(camPos, worldPos));
@@ -324,19 +342,16 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
     // to the right and one pixel down (exact for a planar triangle; no quad, no neighbour lane needed)
     UvGrad grad = {0.0f, 0.0f, 0.0f, 0.0f};
     if (FULL && D.tex_any_mips) {
-        const float u0 = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u, v0 = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
         float bx[3], by[3];
         barycentrics<false>(D, c, pxc + 1.0f, pyc, bx);
         barycentrics<false>(D, c, pxc, pyc + 1.0f, by);
-        grad.dudx = ((bx[0] * vv[0].u + bx[1] * vv[1].u) + bx[2] * vv[2].u) - u0;
-        grad.dvdx = ((bx[0] * vv[0].v + bx[1] * vv[1].v) + bx[2] * vv[2].v) - v0;
-        grad.dudy = ((by[0] * vv[0].u + by[1] * vv[1].u) + by[2] * vv[2].u) - u0;
-        grad.dvdy = ((by[0] * vv[0].v + by[1] * vv[1].v) + by[2] * vv[2].v) - v0;
+        grad.dudx = ((bx[0] * uvk[0][0] + bx[1] * uvk[1][0]) + bx[2] * uvk[2][0]) - u;
+        grad.dvdx = ((bx[0] * uvk[0][1] + bx[1] * uvk[1][1]) + bx[2] * uvk[2][1]) - v;
+        grad.dudy = ((by[0] * uvk[0][0] + by[1] * uvk[1][0]) + by[2] * uvk[2][0]) - u;
+        grad.dvdy = ((by[0] * uvk[0][1] + by[1] * uvk[1][1]) + by[2] * uvk[2][1]) - v;
     }
-    if (FULL && D.program == 3) return shade_pbr(D, b, vv, worldPos, V, N, grad);
+    if (FULL && D.program == 3) return shade_pbr(D, b, vi, u, v, worldPos, V, N, grad);
     // pixel/model_full.hlsl:85-150
-    const float u = (b[0] * vv[0].u + b[1] * vv[1].u) + b[2] * vv[2].u;
-    const float v = (b[0] * vv[0].v + b[1] * vv[1].v) + b[2] * vv[2].v;
     const f4 baseColor = {ldcf(cb(D.material), 0), ldcf(cb(D.material), 4), ldcf(cb(D.material), 8), ldcf(cb(D.material), 12)};
     const float roughness = ldcf(cb(D.material), 20), ao = ldcf(cb(D.material), 24);
     const f4 albedoSample = sample_texture<FULL>(D, 0, u, v, grad);
@@ -346,8 +361,9 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
     const bool hasNormalMap = length3(ncm1) > 0.01f;                          // :94-95
     if (hasNormalMap) {                                                      // GetWorldNormal :63-83
         const f3 ns = {nc.x * 2.0f - 1.0f, nc.y * 2.0f - 1.0f, nc.z * 2.0f - 1.0f};
-        const f3 T = normalize3(interp3(b, vv[0].tangent, vv[1].tangent, vv[2].tangent));
-        const f3 Bt = normalize3(interp3(b, vv[0].bitangent, vv[1].bitangent, vv[2].bitangent));
+        f3 Ti, Bi;
+        interp_tangent_frame(D, vi, b, Ti, Bi);
+        const f3 T = normalize3(Ti), Bt = normalize3(Bi);
         N = normalize3(add3(add3(scale3(T, ns.x), scale3(Bt, ns.y)), scale3(N, ns.z)));
     }
     const f3 ambient = scale3(scale3(albedo, 0.03f), ao);
