@@ -363,6 +363,7 @@ def main():
         shaded, covered, _scopes = dev.fragment_stats()
     dev.reset_kernel_times()
     stats = dev.stats()
+    rig.destroy(comm)        # (frees its queue lanes: a second device beside it would share the 4 hardware queues with it)
 
     extras = {}
     if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
@@ -462,7 +463,6 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
-    rig.destroy(comm)
     if world > 1:
         dist.destroy_process_group()
 
