@@ -246,6 +246,24 @@ def main():
             self.counter += 1
             return i
 
+        def add_groups(self, per_submit):
+            """one more group of `per_submit` frames (own targets and command buffers) per queue lane of this device"""
+            lanes = len(self.groups)
+            wrap = make_wrap()
+            added = []
+            for g in range(lanes):
+                grp = []
+                for _ in range(per_submit):
+                    frame = torch.zeros((scene.height, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
+                    target = m.Image(self.dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
+                    self.frames.append(frame)
+                    sl = m.SceneResources(self.dev, scene, fmt, color_image=target, wrap_buffers=wrap)
+                    sl.cmd.set_queue_lane(g)
+                    self.slots.append(sl)
+                    grp.append(sl)
+                added.append(grp)
+            return added
+
         def submit_group(self):
             """per_submit frames in one mirhi_queue_submit call; returns the slots rendered"""
             g = self.groups[(self.counter // self.per_submit) % len(self.groups)]
@@ -363,48 +381,49 @@ def main():
         shaded, covered, _scopes = dev.fragment_stats()
     dev.reset_kernel_times()
     stats = dev.stats()
-    rig.destroy(comm)        # (frees its queue lanes: a second device beside it would share the 4 hardware queues with it)
-
     extras = {}
     if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
         # the same frame loop with 8 command buffers per mirhi_queue_submit call (vkQueueSubmit with several command buffers): the
-        # frames of a call share one batch of launches.  Reported beside the headline, which keeps one frame per submit.
+        # frames of a call share one batch of launches.  Same device and queue lanes (a second device would be dealt other hardware
+        # queues); reported beside the headline, which keeps one frame per submit.
         try:
-            br = Rig(nfif, per_submit=8)
-            for _ in range(max(8, fps // 8 // 4)):
-                br.submit_group()
-            br.dev.wait_idle()
+            groups = rig.add_groups(8)
+            for i in range(max(8, fps // 8 // 4)):
+                dev.submit([sl.cmd for sl in groups[i % len(groups)]])
+            dev.wait_idle()
             nb = max(16, 4 * fps // 8)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(nb):
-                br.submit_group()
-            br.dev.wait_idle()
+            for i in range(nb):
+                dev.submit([sl.cmd for sl in groups[i % len(groups)]])
+            dev.wait_idle()
             d1 = time.perf_counter() - t1
             extras["batched_submit"] = {"value": round(tris * nb * 8 / d1 / 1e6, 3), "unit": "Mtris/s", "frames_per_submit": 8, "queue_lanes": nfif,
                                         "frames": nb * 8, "us_per_frame": round(1e6 * d1 / (nb * 8), 4)}
-            br.destroy()
         except Exception as e:
             extras["batched_submit"] = {"error": repr(e)}
-    if world > 1 and not args.no_extras and not args.profile_pass_only:
+    if world > 1 and split and not args.no_extras and not args.profile_pass_only:
         try:
-            # the same workload, whole frame on ONE GPU (every rank renders its own copy: no exchange): the N = 1 point of the curve
-            ref = Rig(min(4, max(1, args.frames_in_flight))) if split else None
-            if ref is not None:
-                n = max(8, fps)
-                for _ in range(n // 4):
-                    ref.slots[ref.next_slot()].render()
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(n):
-                    ref.slots[ref.next_slot()].render()
-                barrier()
-                d1 = max_over_ranks(time.perf_counter() - t1)
-                extras["one_gpu_same_workload"] = {"value": round(tris * n / d1 / 1e6, 3), "unit": "Mtris/s", "frames": n,
-                                                   "note": "whole frame per GPU, no split, no exchange (all ranks at once, slowest rank)"}
-                ref.destroy()
+            # the same workload, whole frame on ONE GPU (every rank renders its own unsplit copy, no exchange): the N = 1 point of the
+            # curve.  Same device and queue lanes, re-recorded without the split.
+            dev.wait_idle()
+            dev.set_tile_split(0, 1)
+            for sl in rig.slots:
+                sl.record()
+            n = max(8, fps)
+            for _ in range(max(1, n // 4 // per_submit)):
+                rig.submit_group()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n // per_submit):
+                rig.submit_group()
+            barrier()
+            d1 = max_over_ranks(time.perf_counter() - t1)
+            extras["one_gpu_same_workload"] = {"value": round(tris * (n // per_submit) * per_submit / d1 / 1e6, 3), "unit": "Mtris/s", "frames": (n // per_submit) * per_submit,
+                                               "note": "whole frame per GPU, no split, no exchange (all ranks at once, slowest rank)"}
         except Exception as e:          # never let a secondary measurement take the primary line down
             extras["one_gpu_same_workload"] = {"error": repr(e)}
+    rig.destroy(comm)        # (frees its queue lanes: a second device beside it would share the 4 hardware queues with it)
 
     if rank == 0:
         frames_total = args.steps * fps * (1 if split or world == 1 else world)
