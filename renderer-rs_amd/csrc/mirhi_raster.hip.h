@@ -40,7 +40,6 @@ __device__ __forceinline__ int64_t mul24x24(int32_t a, int32_t b) {
 // box: the triangle's inclusive pixel box clamped to the tile, bx0 | bx1 << 8 | by0 << 16 | by1 << 24 (bx0 > bx1 or by0 > by1: it
 // misses the tile); boxed: 0x80000000 if a scissor cut the box (the pixel loops then test it per pixel)
 struct TileTri { int32_t X[3], Y[3]; uint32_t box, z0, zx, zy, idk, boxed; };
-constexpr uint32_t REC_FLOAT_OK = 0x40000000u;      // bit 30 of a tile record's mask word (bit 31: a pixel box applies; bits 0..15: block mask)
 __device__ __forceinline__ uint32_t clamp_box(int32_t bx0, int32_t bx1, int32_t by0, int32_t by1) {
     // an empty intersection keeps lo > hi after the clamps: lo in [0, 32], hi in [-1, 31]
     bx0 = bx0 < 0 ? 0 : (bx0 > TILE ? TILE : bx0); by0 = by0 < 0 ? 0 : (by0 > TILE ? TILE : by0);
@@ -50,8 +49,6 @@ __device__ __forceinline__ uint32_t clamp_box(int32_t bx0, int32_t bx1, int32_t 
 
 // (opx, opy): the tile's origin in the pixel frame T.X / T.Y are given in -- (0, 0) for a bin record, which is relative to its
 // tile; the tile's position in the target for a big-list record, whose coordinates are absolute.  Wave-uniform.
-// FLOAT_OUT: Q_i, A_i, B_i of a REC_FLOAT_OK record leave as binary32 numbers (Q clamped to +-2^23), the form raster_record<.., FLT> reads
-template <bool FLOAT_OUT = false>
 __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
     const int32_t Ptx = 256 * opx + 128, Pty = 256 * opy + 128;           // tile origin pixel centre, 1/256 px
     int32_t A[3], B[3], Q[3];
@@ -99,23 +96,10 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     const float inv256 = 1.0f / 256.0f;
     const float dxt = ((float)opx + 0.5f) - (float)T.X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
     const float dyt = ((float)opy + 0.5f) - (float)T.Y[0] * inv256;
-    if (FLOAT_OUT && !T.boxed) {
-        const int32_t lim = 1 << 23;
-#define MIRHI_QF(v) __float_as_uint((float)max(min((v), lim), -lim))
-#define MIRHI_IF(v) __float_as_uint((float)(v))
-        out[0] = make_uint4(MIRHI_QF(Q[0]), MIRHI_QF(Q[1]), MIRHI_QF(Q[2]), MIRHI_IF(A[0]));
-        out[1] = make_uint4(MIRHI_IF(A[1]), MIRHI_IF(A[2]), MIRHI_IF(B[0]), MIRHI_IF(B[1]));
-        out[2] = make_uint4(MIRHI_IF(B[2]), __float_as_uint(dxt), __float_as_uint(dyt), T.z0);
-#undef MIRHI_QF
-#undef MIRHI_IF
-    } else {
     out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
     out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
     out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), T.z0);
-    }
-    // REC_FLOAT_OK: every |A_i|, |B_i| is below 2^16 (differences of 16-bit coordinates), so the pixel loops may evaluate the edge
-    // functions in binary32 without losing a bit (raster_record<.., FLT>); a scissor-cut record keeps the integer path
-    out[3] = make_uint4(T.zx, T.zy, T.idk, mask | T.boxed | (T.boxed ? 0u : REC_FLOAT_OK));
+    out[3] = make_uint4(T.zx, T.zy, T.idk, mask | T.boxed);
     box = T.box;
     return mask != 0;
 }
@@ -227,33 +211,17 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return d;
 }
 
-// FLT: the record's Q_i, A_i, B_i are binary32 numbers (raster_list converts REC_FLOAT_OK records when it stages them) and the
-// edge functions are evaluated with FMAs and float adds -- exactly: |A_i|, |B_i| < 2^16, ix, iy <= 31 and Q_i clamped to +-2^23 (the
-// sign of Q_i + A_i ix + B_i iy is the sign of Q_i beyond that) keep every intermediate an integer below 2^24, and a zero comes out
-// as +0, so the sign bit is the integer result's.  Why: v_fma_f32 / v_add_f32 issue at 2.5 cycles per wave on this part,
-// v_mad_i32_i24 / v_lshl_add_u32 at 4.3 (tools/microbench/README.md) -- a fifth of the instruction time of this loop, which is what the frame
-// loop of the headline workload is bound by.
-template <int KEYED, bool BOXED, bool FLT = false>
+template <int KEYED, bool BOXED>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
                                               float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
     const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
     const int32_t B0 = (int32_t)r.w1.z, B1 = (int32_t)r.w1.w, B2 = (int32_t)r.w2.x;
-    const float fA0 = __uint_as_float(r.w0.w), fA1 = __uint_as_float(r.w1.x), fA2 = __uint_as_float(r.w1.y);
-    const float fB0 = __uint_as_float(r.w1.z), fB1 = __uint_as_float(r.w1.w), fB2 = __uint_as_float(r.w2.x);
     const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
     const uint32_t idk = r.w3.z;
     const uint32_t m = __builtin_amdgcn_readfirstlane(r.w3.w);
-    int32_t s0 = 0, s1 = 0, s2 = 0;
-    float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-    if (FLT) {
-        f0 = __builtin_fmaf(fB0, fiy0, __builtin_fmaf(fA0, fix0, __uint_as_float(r.w0.x)));
-        f1 = __builtin_fmaf(fB1, fiy0, __builtin_fmaf(fA1, fix0, __uint_as_float(r.w0.y)));
-        f2 = __builtin_fmaf(fB2, fiy0, __builtin_fmaf(fA2, fix0, __uint_as_float(r.w0.z)));
-    } else {
-        s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)r.w0.x));
-        s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)r.w0.y));
-        s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
-    }
+    const int32_t s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)r.w0.x));
+    const int32_t s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)r.w0.y));
+    const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
     // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
 #pragma unroll
@@ -262,14 +230,7 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
         if (!(m & (qbit0 << (by * 4 + bx)))) continue;
         // edge functions at this block: one shift-add per edge and step (v_lshl_add_u32), no shared shift results
         int32_t sgn;                                         // covered <=> sign bit clear
-        if (FLT) {
-            const float e8 = (float)BLOCK;
-            float g0 = f0, g1 = f1, g2 = f2;
-            if (bx) { g0 = __builtin_fmaf(fA0, e8, g0); g1 = __builtin_fmaf(fA1, e8, g1); g2 = __builtin_fmaf(fA2, e8, g2); }
-            if (by) { g0 = __builtin_fmaf(fB0, e8, g0); g1 = __builtin_fmaf(fB1, e8, g1); g2 = __builtin_fmaf(fB2, e8, g2); }
-            sgn = (int32_t)(__float_as_uint(g0) | __float_as_uint(g1) | __float_as_uint(g2));
-        }
-        else if (!bx && !by) sgn = s0 | s1 | s2;
+        if (!bx && !by) sgn = s0 | s1 | s2;
         else if (bx && !by) sgn = step8(A0, s0) | step8(A1, s1) | step8(A2, s2);
         else if (!bx && by) sgn = step8(B0, s0) | step8(B1, s1) | step8(B2, s2);
         else sgn = step8(B0, step8(A0, s0)) | step8(B1, step8(A1, s1)) | step8(B2, step8(A2, s2));
@@ -320,15 +281,8 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
     for (uint32_t g = 0; g < n; g += 64u) {
         const uint32_t j = g + lane;
         const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
-        const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u, flt = (mymask & REC_FLOAT_OK) != 0u;
-        uint64_t fbits = __ballot(rel && !boxed && flt);       // records staged in float form (every bin record): the fast-rate loop
-        while (fbits) {
-            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)fbits) - 1);
-            fbits &= fbits - 1;
-            const RecRegs cur = load_rec(lds_rec, cur_j);
-            raster_record<KEYED, false, true>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
-        }
-        uint64_t bits = __ballot(rel && !boxed && !flt);      // big-list records: integer edge functions
+        const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u;
+        uint64_t bits = __ballot(rel && !boxed);
         while (bits) {
             const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
             bits &= bits - 1;
@@ -468,7 +422,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
                 hit = !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
                 if (hit) hit = make_tile_rec(rec, box, w0, w1, w2, (int32_t)txl, (int32_t)tyl);
             }
-            if (BINS && hit) hit = make_tile_rec<!TP>(rec, box, T);       // (the triangle-parallel path walks integer records: those variants convert when they stage)
+            if (BINS && hit) hit = make_tile_rec(rec, box, T);
         }
         bool small = false, boxed = false;
         if (hit) {
@@ -492,18 +446,6 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         wbase = __builtin_amdgcn_readfirstlane(wbase);
         if (hit) {
             const uint32_t slot = wbase + (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
-            if (TP && (rec[3].w & REC_FLOAT_OK)) {
-                // staged for the pixel loops in float form (raster_record<.., FLT>): Q clamped to +-2^23 -- beyond that its sign is the
-                // edge function's sign everywhere in the tile -- so that every sum stays an integer below 2^24
-                const int32_t lim = 1 << 23;
-#define MIRHI_QF(v) __float_as_uint((float)max(min((int32_t)(v), lim), -lim))
-#define MIRHI_IF(v) __float_as_uint((float)(int32_t)(v))
-                rec[0] = make_uint4(MIRHI_QF(rec[0].x), MIRHI_QF(rec[0].y), MIRHI_QF(rec[0].z), MIRHI_IF(rec[0].w));
-                rec[1] = make_uint4(MIRHI_IF(rec[1].x), MIRHI_IF(rec[1].y), MIRHI_IF(rec[1].z), MIRHI_IF(rec[1].w));
-                rec[2].x = MIRHI_IF(rec[2].x);
-#undef MIRHI_QF
-#undef MIRHI_IF
-            }
             lds_rec[slot * 4u + 0] = rec[0]; lds_rec[slot * 4u + 1] = rec[1];
             lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
             if (!TP) lds_box[slot] = box;
