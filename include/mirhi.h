@@ -239,6 +239,16 @@ mirhi_result mirhi_cmd_set_scissor(mirhi_cmd* cmd, const mirhi_rect2d* scissor);
 mirhi_result mirhi_cmd_draw(mirhi_cmd* cmd, uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance); /* draw :583 */
 mirhi_result mirhi_cmd_draw_indexed(mirhi_cmd* cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance); /* draw_indexed :610 */
 
+/* draw_indirect :630 / draw_indexed_indirect :646 (VkDrawIndirectCommand: 4 x u32; VkDrawIndexedIndirectCommand: 4 x u32 + i32 vertexOffset at
+ * word 3).  The arguments live in a device buffer; this build READS THEM WHEN THE COMMAND IS RECORDED (one synchronous device -> host copy of
+ * draw_count x stride bytes) and records the equivalent direct draws -- Vulkan reads them when the command executes, so a command buffer
+ * whose indirect arguments change afterwards must be recorded again.  stride: multiple of 4, >= 16 / 20 when draw_count > 1. */
+mirhi_result mirhi_cmd_draw_indirect(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, uint32_t draw_count, uint32_t stride);
+mirhi_result mirhi_cmd_draw_indexed_indirect(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, uint32_t draw_count, uint32_t stride);
+/* push_constants / push_constants_bytes :732-769.  Validated as Vulkan does (offset and length multiples of 4, offset + length <= 128) and kept
+ * with the command buffer; the programs on this path read none (no HLSL file of the reference declares a push-constant block). */
+mirhi_result mirhi_cmd_push_constants(mirhi_cmd* cmd, uint32_t stage_flags, uint32_t offset, const void* data, uint32_t len);
+
 /* ---- submit + sync: vkQueueSubmit (renderer.rs:407-424, frame_manager.rs:439-462), Fence (sync.rs:168-298) */
 mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence /* may be NULL */);
 mirhi_result mirhi_fence_create(mirhi_device* dev, uint32_t signaled, mirhi_fence** out);   /* Fence::new :168 */

@@ -206,6 +206,9 @@ _SIGNATURES = {
     "mirhi_cmd_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mirhi_cmd_destroy": (C.c_int32, [C.c_void_p]),
     "mirhi_cmd_set_queue_lane": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "mirhi_cmd_draw_indirect": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "mirhi_cmd_draw_indexed_indirect": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "mirhi_cmd_push_constants": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]),
     "mirhi_cmd_begin": (C.c_int32, [C.c_void_p]),
     "mirhi_cmd_begin_reusable": (C.c_int32, [C.c_void_p]),
     "mirhi_cmd_end": (C.c_int32, [C.c_void_p]),
@@ -605,6 +608,16 @@ class CommandBuffer:
     def set_scissor(self, x, y, width, height):
         sc = Rect2D(x, y, width, height)
         check(lib().mirhi_cmd_set_scissor(self.handle, C.byref(sc)))
+
+    def draw_indirect(self, buffer: Buffer, offset: int, draw_count: int, stride: int):
+        check(lib().mirhi_cmd_draw_indirect(self.handle, buffer.handle, offset, draw_count, stride))
+
+    def draw_indexed_indirect(self, buffer: Buffer, offset: int, draw_count: int, stride: int):
+        check(lib().mirhi_cmd_draw_indexed_indirect(self.handle, buffer.handle, offset, draw_count, stride))
+
+    def push_constants(self, stage_flags: int, offset: int, data: bytes):
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if data else None
+        check(lib().mirhi_cmd_push_constants(self.handle, stage_flags, offset, buf, len(data)))
 
     def set_queue_lane(self, lane: int):
         check(lib().mirhi_cmd_set_queue_lane(self.handle, lane))

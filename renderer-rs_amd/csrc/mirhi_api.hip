@@ -193,6 +193,7 @@ struct mirhi_cmd {
     struct { mirhi_buffer* buf; uint64_t offset, range; } uniforms[MIRHI_SLOT_COUNT] = {};
     mirhi_image* textures[MIRHI_TEXTURE_COUNT] = {};
     bool has_viewport = false, has_scissor = false;
+    uint8_t push_constants[128] = {0};     // vkCmdPushConstants: kept, read by no program on this path
     mirhi_viewport viewport{};
     mirhi_rect2d scissor{};
     // device-side plan, built at end()
@@ -973,6 +974,48 @@ extern "C" mirhi_result mirhi_cmd_draw(mirhi_cmd* cmd, uint32_t vertex_count, ui
 extern "C" mirhi_result mirhi_cmd_draw_indexed(mirhi_cmd* cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance) {
     (void)first_instance;
     return record_draw(cmd, true, index_count, instance_count, first_index, vertex_offset);
+}
+
+// draw_indirect / draw_indexed_indirect (command.rs:630-661): the arguments are fetched from the device buffer now, at record time
+static mirhi_result record_indirect(mirhi_cmd* cmd, bool indexed, mirhi_buffer* buffer, uint64_t offset, uint32_t draw_count, uint32_t stride) {
+    REQUIRE_RECORDING(cmd); NULL_CHECK(buffer, "buffer");
+    if (buffer->dev != cmd->dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: indirect buffer belongs to another device");
+    const uint32_t words = indexed ? 5u : 4u;
+    if (draw_count == 0) return MIRHI_OK;
+    if ((offset & 3u) || (draw_count > 1 && (stride < words * 4u || (stride & 3u))))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: indirect offset %llu / stride %u must be multiples of 4 (stride >= %u)", (unsigned long long)offset, stride, words * 4u);
+    const uint64_t step = draw_count > 1 ? stride : words * 4u;
+    const uint64_t span = (uint64_t)(draw_count - 1) * step + words * 4u;
+    if (offset + span > buffer->size || offset + span < offset)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: indirect draws read [%llu, %llu) beyond the buffer (%llu bytes)", (unsigned long long)offset,
+                    (unsigned long long)(offset + span), (unsigned long long)buffer->size);
+    std::vector<uint8_t> host(span);
+    { mirhi_result r0 = sync_all_lanes(cmd->dev); if (r0 != MIRHI_OK) return r0; }
+    HIP_TRY(hipMemcpyAsync(host.data(), buffer->ptr + offset, span, hipMemcpyDeviceToHost, cmd->dev->stream));
+    HIP_TRY(hipStreamSynchronize(cmd->dev->stream));
+    for (uint32_t i = 0; i < draw_count; i++) {
+        uint32_t a[5] = {0, 0, 0, 0, 0};
+        memcpy(a, host.data() + (size_t)i * step, words * 4u);
+        const mirhi_result r = indexed ? record_draw(cmd, true, a[0], a[1], a[2], (int32_t)a[3]) : record_draw(cmd, false, a[0], a[1], a[2], 0);
+        if (r != MIRHI_OK) return r;
+    }
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_cmd_draw_indirect(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, uint32_t draw_count, uint32_t stride) {
+    return record_indirect(cmd, false, buffer, offset, draw_count, stride);
+}
+extern "C" mirhi_result mirhi_cmd_draw_indexed_indirect(mirhi_cmd* cmd, mirhi_buffer* buffer, uint64_t offset, uint32_t draw_count, uint32_t stride) {
+    return record_indirect(cmd, true, buffer, offset, draw_count, stride);
+}
+extern "C" mirhi_result mirhi_cmd_push_constants(mirhi_cmd* cmd, uint32_t stage_flags, uint32_t offset, const void* data, uint32_t len) {
+    REQUIRE_RECORDING(cmd);
+    (void)stage_flags;
+    if (len == 0) return MIRHI_OK;
+    NULL_CHECK(data, "data");
+    if ((offset & 3u) || (len & 3u) || (uint64_t)offset + len > sizeof cmd->push_constants)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: push constants offset %u + size %u must be multiples of 4 within %zu bytes", offset, len, sizeof cmd->push_constants);
+    memcpy(cmd->push_constants + offset, data, len);
+    return MIRHI_OK;
 }
 
 // ---- end(): size the workspace and build the launch plan ------------------------------------------

@@ -721,3 +721,62 @@ def test_comm_single_rank(mirhi, device, scenes):
     comm.destroy()
     res.destroy()
     dev.destroy()
+
+
+def test_indirect_draws_and_push_constants(mirhi, oracle, device, scenes):
+    """draw_indirect / draw_indexed_indirect (command.rs:630-661) with the arguments in a GPU-only Indirect buffer (buffer.rs:86-100),
+    filled through a staging upload: the frame equals the one the same draws give when recorded directly.  push_constants
+    (command.rs:732-769) is validated and otherwise without effect: no program of the path reads a push-constant block."""
+    import struct
+    scene = scenes.random_triangles(900, 400, 260, seed=15)
+    d = scene.draws[0]
+    ref = oracle.render(scene, want_bgra8=False)
+    color = mirhi.Image(device, scene.width, scene.height, mirhi.Format.R32G32B32A32_SFLOAT)
+    prim = mirhi.Image(device, scene.width, scene.height, mirhi.Format.R32_UINT)
+    pipe = (mirhi.GraphicsPipelineBuilder().vertex_shader(mirhi.Program.TRIANGLE).fragment_shader(mirhi.Program.TRIANGLE)
+            .vertex_binding(24).vertex_attributes(mirhi.TRIANGLE_VERTEX_OFFSETS).color_attachment_format(mirhi.Format.R32G32B32A32_SFLOAT)
+            .cull_mode(d.cull_mode).depth_test_enable(True).depth_write_enable(True).depth_attachment_format(mirhi.Format.D32_SFLOAT).build(device))
+    vb = mirhi.Buffer.new_with_data(device, mirhi.BufferUsage.Vertex, d.vertices)
+    # three non-indexed draws (300 triangles each, the second one behind a gap in the buffer: stride 32), then the same as indexed draws
+    args = b"".join(struct.pack("<4I", 900, 1, 900 * k, 0) + b"\xEE" * 16 for k in range(3))
+    ind = mirhi.Buffer(device, mirhi.BufferUsage.Indirect, len(args) + 64)
+    with pytest.raises(mirhi.RhiError):
+        ind.write_data(0, args)                          # GPU-only memory is not mapped (buffer.rs:266-268)
+    ind.upload_via_staging(args)
+    cmd = mirhi.CommandBuffer(device)
+
+    def record(indirect):
+        cmd.begin_reusable()
+        cmd.begin_rendering(color, clear_color=scene.clear_color, prim_id=prim)
+        cmd.set_viewport(0.0, 0.0, float(scene.width), float(scene.height)); cmd.set_scissor(0, 0, scene.width, scene.height)
+        cmd.bind_pipeline(pipe); cmd.bind_vertex_buffers(0, [vb], [0])
+        cmd.push_constants(1, 16, struct.pack("<4f", 1, 2, 3, 4))
+        if indirect:
+            cmd.draw_indirect(ind, 0, 3, 32)
+        else:
+            for k in range(3):
+                cmd.draw(900, 1, 900 * k, 0)
+        cmd.end_rendering(); cmd.end()
+
+    out = []
+    for indirect in (False, True):
+        record(indirect)
+        device.submit([cmd]); device.wait_idle()
+        out.append((color.read(), prim.read()))
+    assert np.array_equal(out[0][1], ref["prim"]) and np.array_equal(out[1][1], ref["prim"]) and np.array_equal(out[0][0], out[1][0])
+    # validation: unaligned offset, stride too small, range beyond the buffer, push constants beyond 128 bytes / unaligned
+    cmd.begin_reusable(); cmd.begin_rendering(color, prim_id=prim)
+    cmd.set_viewport(0.0, 0.0, float(scene.width), float(scene.height)); cmd.set_scissor(0, 0, scene.width, scene.height)
+    cmd.bind_pipeline(pipe); cmd.bind_vertex_buffers(0, [vb], [0])
+    for bad in ((2, 1, 16), (0, 2, 12), (len(args) + 60, 1, 16), (0, 9, 32)):
+        with pytest.raises(mirhi.RhiError):
+            cmd.draw_indirect(ind, *bad)
+    with pytest.raises(mirhi.RhiError):
+        cmd.draw_indexed_indirect(ind, 0, 1, 20)          # no index buffer bound
+    for off, n in ((126, 4), (0, 132), (4, 6)):
+        with pytest.raises(mirhi.RhiError):
+            cmd.push_constants(1, off, bytes(n))
+    cmd.draw_indirect(ind, 0, 0, 0)                        # draw_count 0: nothing
+    cmd.end_rendering(); cmd.end()
+    for o in (cmd, ind, vb, pipe, prim, color):
+        o.destroy()
