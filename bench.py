@@ -287,7 +287,7 @@ def main():
         fps = (fps // per_submit + 1) * per_submit
     if split:
         nfif = min(nfif, 2)
-        rows = multigpu.padded_rows(scene.height, world) if not use_abi_gather else scene.height
+        rows = multigpu.padded_rows(scene.height, world)      # (padding is only needed by the torch all-gather, kept as the way out)
         rig = Rig(nfif, band=(rank, world), rows=rows, per_submit=per_submit)
     else:
         rig = Rig(nfif, per_submit=per_submit)
@@ -297,11 +297,29 @@ def main():
     if use_abi_gather:
         # the 128-byte RCCL id travels over the launcher's control channel; the data path is the C ABI alone
         uid = torch.zeros(m.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(m.Comm.unique_id()), dtype=torch.uint8))
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        try:
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(m.Comm.unique_id()), dtype=torch.uint8))
+        except Exception as e:
+            print(f"bench.py: rank {rank}: mirhi_comm_unique_id failed: {e!r}", file=sys.stderr, flush=True)
+            ok.zero_()
         dist.broadcast(uid, src=0)
-        comm = m.Comm(dev, bytes(uid.cpu().numpy().tobytes()), rank, world)
-        rccl_ranks = comm.world()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()):
+            try:
+                comm = m.Comm(dev, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                rccl_ranks = comm.world()
+            except Exception as e:
+                print(f"bench.py: rank {rank}: mirhi_comm_create failed: {e!r}", file=sys.stderr, flush=True)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            # every rank agrees: the exchange goes through torch.distributed's RCCL all-gather instead (same wire, other caller); the
+            # line says so in config.parallelism
+            if comm is not None:
+                comm.destroy()
+            comm, rccl_ranks = None, world
     algo = m.GatherAlgo.DIRECT if args.gather_algo == "direct" else m.GatherAlgo.BROADCAST
 
     def frames():
