@@ -102,6 +102,25 @@ impl CommandBuffer {
     pub fn draw_indexed(&self, index_count: u32, instance_count: u32, first_index: u32, vertex_offset: i32, first_instance: u32) -> RhiResult<()> {   // :610
         check(unsafe { mirhi_sys::mirhi_cmd_draw_indexed(self.raw, index_count, instance_count, first_index, vertex_offset, first_instance) })
     }
+    /// Arguments are read from `buffer` when this call records (libmirhi latches them; Vulkan reads them at execution).
+    pub fn draw_indirect(&self, buffer: &Buffer, offset: u64, draw_count: u32, stride: u32) -> RhiResult<()> {              // :630
+        check(unsafe { mirhi_sys::mirhi_cmd_draw_indirect(self.raw, buffer.raw, offset, draw_count, stride) })
+    }
+    pub fn draw_indexed_indirect(&self, buffer: &Buffer, offset: u64, draw_count: u32, stride: u32) -> RhiResult<()> {      // :646
+        check(unsafe { mirhi_sys::mirhi_cmd_draw_indexed_indirect(self.raw, buffer.raw, offset, draw_count, stride) })
+    }
+    pub fn push_constants_bytes(&self, stages: u32, offset: u32, data: &[u8]) -> RhiResult<()> {                            // :752
+        check(unsafe { mirhi_sys::mirhi_cmd_push_constants(self.raw, stages, offset, data.as_ptr() as *const std::os::raw::c_void, data.len() as u32) })
+    }
+    pub fn push_constants<T: Copy>(&self, stages: u32, offset: u32, data: &T) -> RhiResult<()> {                            // :732
+        let bytes = unsafe { std::slice::from_raw_parts(data as *const T as *const u8, std::mem::size_of::<T>()) };
+        self.push_constants_bytes(stages, offset, bytes)
+    }
+    /// Queue lane (`Device::set_queue_lanes`) this command buffer is submitted on; several command buffers handed to one
+    /// `Queue::submit` that are frames of the same shape run as one batch of launches on the first one's lane.
+    pub fn set_queue_lane(&self, lane: u32) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_cmd_set_queue_lane(self.raw, lane) })
+    }
 }
 
 impl Drop for CommandBuffer {
