@@ -284,9 +284,11 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
         const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u;
         uint64_t bits = __ballot(rel && !boxed);
         while (bits) {
-            const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bits) - 1);
-            bits &= bits - 1;
-            const RecRegs cur = load_rec(lds_rec, cur_j);
+            const uint32_t bit = (uint32_t)(__ffsll((long long)bits) - 1);
+            // clear the bit with one scalar instruction (the compiler's `bits &= bits - 1` is add, addc, and: the scalar unit issues
+            // at the vector unit's rate on this part, and this loop runs once per record and wave)
+            asm("s_bitset0_b64 %0, %1" : "+s"(bits) : "s"(bit));
+            const RecRegs cur = load_rec(lds_rec, g + bit);
             raster_record<KEYED, false>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
         }
         if (!TP) {   // without the triangle-parallel path, scissor-cut triangles (rare) take the per-pixel box test here
