@@ -332,7 +332,9 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
     if (!full) {                                                             // pixel/model.hlsl:29-82
         const f3 albedo = {0.7f, 0.7f, 0.7f};
         const f3 one = {1.0f, 1.0f, 1.0f};
-        const f3 L = normalize3(one);
+        // normalize((1, 1, 1)) is a constant: RN(1 / RN(sqrt(3))) = 0x1.279a740000000p-1 (the oracle's two roundings), not recomputed per pixel
+        const float inv_len = 0x1.279a740000000p-1f;
+        const f3 L = {1.0f * inv_len, 1.0f * inv_len, 1.0f * inv_len};
         const f3 ambient = scale3(scale3(albedo, 0.03f), 1.0f);
         const f3 lighting = blinn_phong(L, V, N, one, albedo, roughness_to_shininess(0.5f));
         const f3 col = add3(ambient, lighting);
