@@ -24,10 +24,12 @@ __device__ __forceinline__ float fpow(float x, float y) { return __builtin_amdgc
 __device__ __forceinline__ f3 fnormalize3(f3 a) { const float r = frsq(dot3(a, a)); return {a.x * r, a.y * r, a.z * r}; }
 #pragma clang fp contract(off)
 
-// (scales the light's colour and feeds no exponent: the 1-ulp reciprocals are far inside the 1e-4 colour bound)
+// IEEE quotients, like the oracle's: a 1-ulp reciprocal here looks harmless (it only scales the light's colour) but a blended draw on
+// top can feed the lit colour back through (1 - dst) factors and a reverse subtract -- the round-2 soak found one such scene in 160,000
+// (seed 2018940 of tools/soak_fuzz.py: one pixel at 1.01e-4) while these two lines used v_rcp_f32.
 __device__ __forceinline__ float attenuation(float distance, float radius) {          // lights.hlsli:63-73
-    const float att = __builtin_amdgcn_rcpf(distance * distance + 1.0f);
-    float falloff = saturatef(1.0f - distance * __builtin_amdgcn_rcpf(radius));
+    const float att = rcp_rn_nb(distance * distance + 1.0f);
+    float falloff = saturatef(1.0f - div_rn_nb(distance, radius));
     falloff = falloff * falloff;
     return att * falloff;
 }

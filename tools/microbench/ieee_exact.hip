@@ -13,8 +13,8 @@ namespace mirhi {
 }
 using namespace mirhi;
 
-__device__ unsigned long long g_bad[5];
-__device__ uint32_t g_first[5][8][3];
+__device__ unsigned long long g_bad[6];
+__device__ uint32_t g_first[6][8][3];
 __device__ uint32_t g_nb_range[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};   // smallest / largest |x| bits of a mismatch of the branch-free rcp, sqrt
 
 __device__ __forceinline__ bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
@@ -56,27 +56,30 @@ __global__ void check_div(uint32_t per_thread) {
         const float c = __uint_as_float(ma), d = __uint_as_float(mb);
         const float p0 = c / d, p1 = div_rn(c, d);
         if (!same(p0, p1)) report(2, ma, mb, p1);
+        const float p2 = div_rn_nb(c, d);               // the branch-free form the fragment programs use, on the same moderate operands
+        if (!same(p0, p2)) report(5, ma, mb, p2);
     }
 }
 int main() {
-    unsigned long long zero[5] = {0, 0, 0, 0, 0};
+    unsigned long long zero[6] = {0, 0, 0, 0, 0, 0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_bad), zero, sizeof zero);
     hipLaunchKernelGGL(check_unary, dim3(4096), dim3(256), 0, 0);
     hipLaunchKernelGGL(check_div, dim3(8192), dim3(256), 0, 0, 2048u);      // 2^21 threads x 2048 x 2 = 2^33 pairs
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
-    unsigned long long bad[5]; uint32_t first[5][8][3]; uint32_t nb[4];
+    unsigned long long bad[6]; uint32_t first[6][8][3]; uint32_t nb[4];
     hipMemcpyFromSymbol(bad, HIP_SYMBOL(g_bad), sizeof bad);
     hipMemcpyFromSymbol(first, HIP_SYMBOL(g_first), sizeof first);
     hipMemcpyFromSymbol(nb, HIP_SYMBOL(g_nb_range), sizeof nb);
-    const char* names[5] = {"rcp_rn vs 1/x (2^32 inputs)", "sqrt_rn vs sqrtf (2^32 inputs)", "div_rn vs a/b (2^33 pairs)",
-                            "rcp_rn_nb vs 1/x (2^32 inputs; denormal operands / results may differ)", "sqrt_rn_nb vs sqrtf (2^32 inputs; operands below 2^-100 may differ)"};
+    const char* names[6] = {"rcp_rn vs 1/x (2^32 inputs)", "sqrt_rn vs sqrtf (2^32 inputs)", "div_rn vs a/b (2^33 pairs)",
+                            "rcp_rn_nb vs 1/x (2^32 inputs; denormal operands / results may differ)", "sqrt_rn_nb vs sqrtf (2^32 inputs; operands below 2^-100 may differ)",
+                            "div_rn_nb vs a/b (2^32 pairs with exponents in [-27, 28]: must be 0)"};
     int rc = 0;
     printf("branch-free forms: mismatches inside the stated range (1/x: normal x, |x| < 2^126; sqrt: x >= 2^-100): rcp |x| bits [%08x, %08x], sqrt |x| bits [%08x, %08x]  (ffffffff, 0 = none)\n", nb[0], nb[1], nb[2], nb[3]);
     if (nb[1] != 0u || nb[3] != 0u) rc = 1;
-    for (int w = 0; w < 5; w++) {
+    for (int w = 0; w < 6; w++) {
         printf("%s: %llu mismatches\n", names[w], bad[w]);
         for (unsigned long long k = 0; k < bad[w] && k < 8; k++) printf("   x=%08x y=%08x got=%08x\n", first[w][k][0], first[w][k][1], first[w][k][2]);
-        if (bad[w] && w < 3) rc = 1;
+        if (bad[w] && (w < 3 || w == 5)) rc = 1;
     }
     return rc;
 }
