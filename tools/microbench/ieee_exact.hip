@@ -35,7 +35,7 @@ __global__ void check_unary() {
         const uint32_t mag = (uint32_t)n & 0x7FFFFFFFu;
         // the branch-free forms: mismatches are expected only where an operand or a result is denormal; keep the range of |x| seen
         if (!same(r0, r2)) { report(3, (uint32_t)n, 0, r2); if (mag >= 0x00800000u && mag < 0x7E800000u) { atomicMin(&g_nb_range[0], mag); atomicMax(&g_nb_range[1], mag); } }
-        if (!same(s0, s2)) { report(4, (uint32_t)n, 0, s2); if (mag >= 0x0D800000u) {      // x >= 2^-100 atomicMin(&g_nb_range[2], mag); atomicMax(&g_nb_range[3], mag); } }
+        if (!same(s0, s2)) { report(4, (uint32_t)n, 0, s2); if (mag >= 0x0D800000u) { atomicMin(&g_nb_range[2], mag); atomicMax(&g_nb_range[3], mag); } }   // (x >= 2^-100)
     }
 }
 __device__ __forceinline__ uint32_t pcg(uint64_t& st) {
