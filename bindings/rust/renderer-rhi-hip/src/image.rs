@@ -34,6 +34,11 @@ impl Image {
     pub fn height(&self) -> u32 { unsafe { mirhi_sys::mirhi_image_height(self.raw) } }
     pub fn size_bytes(&self) -> u64 { unsafe { mirhi_sys::mirhi_image_size_bytes(self.raw) } }
     pub fn mip_levels(&self) -> u32 { unsafe { mirhi_sys::mirhi_image_mip_levels(self.raw) } }
+    /// Sampler state: 1 = trilinear, up to 16 = anisotropic (the device enables `sampler_anisotropy`, device.rs:161-165).
+    pub fn set_max_anisotropy(&self, max_anisotropy: u32) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_image_set_max_anisotropy(self.raw, max_anisotropy) })
+    }
+    pub fn max_anisotropy(&self) -> u32 { unsafe { mirhi_sys::mirhi_image_max_anisotropy(self.raw) } }
 }
 
 impl Drop for Image {

@@ -117,6 +117,12 @@ mirhi_result mirhi_image_read(mirhi_image* img, void* dst, uint64_t len);   /* a
  * trilinearly (LOD from the analytic screen-space UV derivatives), one without bilinearly.  Call again after an upload. */
 mirhi_result mirhi_image_generate_mips(mirhi_image* img);
 uint32_t     mirhi_image_mip_levels(const mirhi_image* img);
+/* Sampler state of a texture (sampler.rs is a stub; Device::new enables `sampler_anisotropy`, device.rs:161-165):
+ * max_anisotropy in [1, 16], 1 = plain trilinear (the default).  Takes effect on textures with a mip chain, for draws recorded
+ * afterwards: N = min(ceil(Pmax / Pmin), max_anisotropy) trilinear taps along the longer axis of the pixel's footprint at
+ * lambda = log2(Pmax / N), averaged (the example filter of the Vulkan specification, "Texel Anisotropic Filtering"). */
+mirhi_result mirhi_image_set_max_anisotropy(mirhi_image* img, uint32_t max_anisotropy);
+uint32_t     mirhi_image_max_anisotropy(const mirhi_image* img);
 uint32_t     mirhi_image_width(const mirhi_image* img);
 uint32_t     mirhi_image_height(const mirhi_image* img);
 int32_t      mirhi_image_format(const mirhi_image* img);

@@ -158,14 +158,8 @@ static v4 sample_level(const uint8_t* level, uint32_t w, uint32_t h, float u, fl
 typedef struct { float dudx, dvdx, dudy, dvdy; } uv_grad;
 /* Without a chain: bilinear.  With one: trilinear, lambda = 0.5 * log2(max(|d(uv*size)/dx|^2, |d(uv*size)/dy|^2)) clamped to
  * [0, levels - 1] (Vulkan 1.3 15.6.7 with the exact footprint axes instead of an approximation) */
-static v4 sample_texture(const oracle_texture* t, float u, float v, const uv_grad* g) {
-    if (!t->rgba8 || t->width == 0 || t->height == 0) { v4 one = {1.0f, 1.0f, 1.0f, 1.0f}; return one; }
-    const uint32_t levels = t->levels ? t->levels : 1u;
-    if (levels <= 1u) return sample_level(t->rgba8, t->width, t->height, u, v, (int)t->srgb);
-    float ax = g->dudx * (float)t->width, bx = g->dvdx * (float)t->height, ay = g->dudy * (float)t->width, by = g->dvdy * (float)t->height;
-    float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
-    float lam = 0.5f * log2f(rx > ry ? rx : ry);
-    if (!(lam > 0.0f)) lam = 0.0f;
+static v4 sample_trilinear(const oracle_texture* t, uint32_t levels, float u, float v, float lam) {
+    if (!(lam > 0.0f)) lam = 0.0f;                              /* magnification, zero footprint, NaN */
     float top = (float)(levels - 1u);
     if (lam > top) lam = top;
     float l0f = floorf(lam), f = lam - l0f;
@@ -176,6 +170,35 @@ static v4 sample_texture(const oracle_texture* t, float u, float v, const uv_gra
     if (l0 + 1u >= levels) return c0;
     v4 c1 = sample_level(level + 4u * (size_t)lw * lh, lw > 1u ? lw >> 1 : 1u, lh > 1u ? lh >> 1 : 1u, u, v, (int)t->srgb);
     v4 r = {c0.x + (c1.x - c0.x) * f, c0.y + (c1.y - c0.y) * f, c0.z + (c1.z - c0.z) * f, c0.w + (c1.w - c0.w) * f};
+    return r;
+}
+/* max_anisotropy > 1 on a texture with a chain (the device enables `sampler_anisotropy`, crates/rhi/src/device.rs:161-165; the
+ * reference never creates a sampler, so the filter is the one the Vulkan specification gives as its example, 16.8 "Texel
+ * Anisotropic Filtering" / VK_EXT_texture_filter_anisotropic): with Pmax / Pmin the longer / shorter footprint axis in texels,
+ * N = min(ceil(Pmax / Pmin), max_anisotropy), lambda = log2(Pmax / N), and the result is the mean of N trilinear taps placed at
+ * (u, v) + (i / (N + 1) - 1/2) * d(u, v)/d(major axis), i = 1..N. */
+static v4 sample_texture(const oracle_texture* t, float u, float v, const uv_grad* g) {
+    if (!t->rgba8 || t->width == 0 || t->height == 0) { v4 one = {1.0f, 1.0f, 1.0f, 1.0f}; return one; }
+    const uint32_t levels = t->levels ? t->levels : 1u;
+    if (levels <= 1u) return sample_level(t->rgba8, t->width, t->height, u, v, (int)t->srgb);
+    float ax = g->dudx * (float)t->width, bx = g->dvdx * (float)t->height, ay = g->dudy * (float)t->width, by = g->dvdy * (float)t->height;
+    float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+    if (t->max_anisotropy <= 1u) return sample_trilinear(t, levels, u, v, 0.5f * log2f(rx > ry ? rx : ry));
+    const int major_x = rx > ry;
+    float pmax = sqrtf(major_x ? rx : ry), pmin = sqrtf(major_x ? ry : rx);
+    float nf = ceilf(pmax / pmin);
+    if (!(nf <= (float)t->max_anisotropy)) nf = (float)t->max_anisotropy;      /* also a zero short axis (inf) and a zero footprint (NaN) */
+    if (!(nf >= 1.0f)) nf = 1.0f;
+    const float lam = log2f(pmax / nf);
+    const float du = major_x ? g->dudx : g->dudy, dv = major_x ? g->dvdx : g->dvdy;
+    v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t n = (uint32_t)nf;
+    for (uint32_t i = 1; i <= n; i++) {
+        const float ti = (float)i / (nf + 1.0f) - 0.5f;
+        v4 s = sample_trilinear(t, levels, u + du * ti, v + dv * ti, lam);
+        acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    }
+    v4 r = {acc.x / nf, acc.y / nf, acc.z / nf, acc.w / nf};
     return r;
 }
 

@@ -50,8 +50,8 @@ typedef struct {
     uint32_t width, height;
     /* SURVEY 8f rank 3 (texture fidelity): levels > 1 = a mip chain follows level 0 (each level max(1, w>>1) x max(1, h>>1))
      * and the texture is sampled trilinearly; srgb = the RGB bytes are sRGB-encoded and decoded to linear when sampled.
-     * 0 levels means 1. */
-    uint32_t levels, srgb;
+     * 0 levels means 1.  max_anisotropy > 1 (at most 16; only with a chain): anisotropic filtering, see sample_texture. */
+    uint32_t levels, srgb, max_anisotropy;
 } oracle_texture;
 
 typedef struct {

@@ -192,6 +192,8 @@ _SIGNATURES = {
     "mirhi_image_upload": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "mirhi_image_read": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "mirhi_image_generate_mips": (C.c_int32, [C.c_void_p]),
+    "mirhi_image_set_max_anisotropy": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "mirhi_image_max_anisotropy": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_mip_levels": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_width": (C.c_uint32, [C.c_void_p]),
     "mirhi_image_height": (C.c_uint32, [C.c_void_p]),
@@ -427,6 +429,14 @@ class Image:
     @property
     def mip_levels(self) -> int:
         return int(lib().mirhi_image_mip_levels(self.handle))
+
+    def set_max_anisotropy(self, max_anisotropy: int):
+        """Sampler state of a texture with a mip chain (include/mirhi.h): 1 = trilinear, up to 16 = anisotropic."""
+        check(lib().mirhi_image_set_max_anisotropy(self.handle, int(max_anisotropy)))
+
+    @property
+    def max_anisotropy(self) -> int:
+        return int(lib().mirhi_image_max_anisotropy(self.handle))
 
     def read(self) -> np.ndarray:
         n = lib().mirhi_image_size_bytes(self.handle)
@@ -736,6 +746,8 @@ class SceneResources:
             img.upload(np.ascontiguousarray(t.rgba8))
             if t.mips:
                 img.generate_mips()
+            if getattr(t, "max_anisotropy", 1) > 1:
+                img.set_max_anisotropy(t.max_anisotropy)
             cache[id(t)] = img
             self.objs.append(img)
             return img

@@ -128,6 +128,7 @@ struct mirhi_image {
     uint8_t* ptr;
     bool owned;
     uint32_t levels = 1;      // mip levels stored contiguously behind level 0 (mirhi_image_generate_mips)
+    uint32_t max_anisotropy = 1;   // sampler state (mirhi_image_set_max_anisotropy): 1 = trilinear
 };
 
 struct mirhi_pipeline {
@@ -545,6 +546,16 @@ extern "C" mirhi_result mirhi_image_generate_mips(mirhi_image* img) {
     img->levels = levels;
     return MIRHI_OK;
 }
+extern "C" uint32_t mirhi_image_max_anisotropy(const mirhi_image* img) { return img ? img->max_anisotropy : 0; }
+extern "C" mirhi_result mirhi_image_set_max_anisotropy(mirhi_image* img, uint32_t max_anisotropy) {
+    NULL_CHECK(img, "image");
+    if (img->format != MIRHI_FORMAT_R8G8B8A8_UNORM && img->format != MIRHI_FORMAT_R8G8B8A8_SRGB)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: anisotropic filtering applies to sampled R8G8B8A8 textures only");
+    if (max_anisotropy < 1u || max_anisotropy > 16u)
+        return fail(MIRHI_ERR_DEVICE, "Vulkan error: maxAnisotropy %u outside [1, 16] (maxSamplerAnisotropy)", max_anisotropy);
+    img->max_anisotropy = max_anisotropy;        // read when a draw is recorded, like the mip chain
+    return MIRHI_OK;
+}
 extern "C" mirhi_result mirhi_image_destroy(mirhi_image* img) {
     NULL_CHECK(img, "image");
     (void)hipSetDevice(img->dev->ordinal);
@@ -945,6 +956,7 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
                     d.tex[t] = ti->ptr; d.tex_w[t] = ti->width; d.tex_h[t] = ti->height; d.tex_levels[t] = ti->levels;
                     if (ti->format == MIRHI_FORMAT_R8G8B8A8_SRGB) d.tex_srgb |= 1u << t;
                     if (ti->levels > 1) d.tex_any_mips = 1;
+                    if (ti->levels > 1) d.tex_aniso |= (ti->max_anisotropy - 1u) << (4 * t);
                 }
         }
     }

@@ -67,7 +67,8 @@ struct DrawDesc {
     int32_t  sx0, sy0, sx1, sy1;  // inclusive scissor (already clamped to render area and extent)
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
     uint32_t vs_words;            // 16-byte words per shaded vertex (3 MODEL, 5 MODEL_FULL, 0 = no vertex pre-pass)
-    uint32_t pad[3];
+    uint32_t tex_aniso;           // bits 4t..4t+3: max_anisotropy - 1 of texture t (0 = trilinear; set only for textures with a chain)
+    uint32_t pad[2];
     const void* vs_out;           // shaded vertices of this draw's vertex buffer (see VsJob), indexed like the vertex buffer
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");

@@ -83,20 +83,8 @@ __device__ __forceinline__ f4 sample_level(const uint32_t* texels, uint32_t w, u
 }
 // screen-space derivatives of the texture coordinates: (u, v) one pixel to the right and one pixel down, minus (u, v)
 struct UvGrad { float dudx, dvdx, dudy, dvdy; };
-// Texture slot `slot` of the draw at (u, v).  Without a mip chain: bilinear (the reference never creates a sampler --
-// sampler.rs is a stub -- so VK_FILTER_LINEAR / REPEAT is this build's stated choice).  With a chain
-// (mirhi_image_generate_mips): trilinear, LOD = log2 of the longer screen-space footprint axis in texels,
-// lambda = 0.5 * log2(max(|d(uv*size)/dx|^2, |d(uv*size)/dy|^2)) clamped to [0, levels - 1].
-template <bool MIPS>
-__device__ __forceinline__ f4 sample_texture(DrawRef D, int slot, float u, float v, const UvGrad& g) {
-    const uint32_t w = D.tex_w[slot], h = D.tex_h[slot], levels = D.tex_levels[slot];
-    const uint32_t* texels = reinterpret_cast<const uint32_t*>(D.tex[slot]);
-    if (!texels || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
-    const bool srgb = MIPS && ((D.tex_srgb >> slot) & 1u);      // (sRGB and mip-mapped textures live in the full-featured variant)
-    if (!MIPS || levels <= 1u) return sample_level(texels, w, h, u, v, srgb);
-    const float ax = g.dudx * (float)w, bx = g.dvdx * (float)h, ay = g.dudy * (float)w, by = g.dvdy * (float)h;
-    const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
-    float lam = 0.5f * __builtin_amdgcn_logf(rx > ry ? rx : ry);          // v_log_f32 is log2
+// trilinear tap at level-of-detail lam (clamped to [0, levels - 1]) -- see oracle sample_trilinear
+__device__ __forceinline__ f4 sample_trilinear(const uint32_t* texels, uint32_t w, uint32_t h, uint32_t levels, float u, float v, float lam, bool srgb) {
     if (!(lam > 0.0f)) lam = 0.0f;                                        // magnification, zero footprint, NaN
     const float top = (float)(levels - 1u);
     if (lam > top) lam = top;
@@ -109,6 +97,43 @@ __device__ __forceinline__ f4 sample_texture(DrawRef D, int slot, float u, float
     const uint32_t* next = texels + (size_t)lw * lh;
     const f4 c1 = sample_level(next, lw > 1u ? lw >> 1 : 1u, lh > 1u ? lh >> 1 : 1u, u, v, srgb);
     return {c0.x + (c1.x - c0.x) * f, c0.y + (c1.y - c0.y) * f, c0.z + (c1.z - c0.z) * f, c0.w + (c1.w - c0.w) * f};
+}
+// Texture slot `slot` of the draw at (u, v).  Without a mip chain: bilinear (the reference never creates a sampler --
+// sampler.rs is a stub -- so VK_FILTER_LINEAR / REPEAT is this build's stated choice).  With a chain
+// (mirhi_image_generate_mips): trilinear, LOD = log2 of the longer screen-space footprint axis in texels,
+// lambda = 0.5 * log2(max(|d(uv*size)/dx|^2, |d(uv*size)/dy|^2)) clamped to [0, levels - 1].
+// With a chain and max_anisotropy > 1 (mirhi_image_set_max_anisotropy; device.rs:161-165 enables the feature): the Vulkan
+// specification's example filter -- N = min(ceil(Pmax / Pmin), max_anisotropy) trilinear taps along the longer footprint axis at
+// lambda = log2(Pmax / N), averaged (oracle sample_texture).  N has to be the oracle's integer, so the square roots and the
+// quotient that decide it are the compiler's IEEE expansions (the path is taken by whole draws, rarely: instructions do not matter).
+template <bool MIPS>
+__device__ __forceinline__ f4 sample_texture(DrawRef D, int slot, float u, float v, const UvGrad& g) {
+    const uint32_t w = D.tex_w[slot], h = D.tex_h[slot], levels = D.tex_levels[slot];
+    const uint32_t* texels = reinterpret_cast<const uint32_t*>(D.tex[slot]);
+    if (!texels || w == 0 || h == 0) return {1.0f, 1.0f, 1.0f, 1.0f};
+    const bool srgb = MIPS && ((D.tex_srgb >> slot) & 1u);      // (sRGB and mip-mapped textures live in the full-featured variant)
+    if (!MIPS || levels <= 1u) return sample_level(texels, w, h, u, v, srgb);
+    const float ax = g.dudx * (float)w, bx = g.dvdx * (float)h, ay = g.dudy * (float)w, by = g.dvdy * (float)h;
+    const float rx = ax * ax + bx * bx, ry = ay * ay + by * by;
+    const uint32_t max_aniso = ((D.tex_aniso >> (4 * slot)) & 15u) + 1u;          // wave-uniform (scalar loads)
+    if (max_aniso <= 1u) return sample_trilinear(texels, w, h, levels, u, v, 0.5f * __builtin_amdgcn_logf(rx > ry ? rx : ry), srgb);   // v_log_f32 is log2
+    const bool major_x = rx > ry;
+    const float pmax = __builtin_sqrtf(major_x ? rx : ry), pmin = __builtin_sqrtf(major_x ? ry : rx);
+    float nf = __builtin_ceilf(pmax / pmin);
+    if (!(nf <= (float)max_aniso)) nf = (float)max_aniso;      // also a zero short axis (inf) and a zero footprint (NaN)
+    if (!(nf >= 1.0f)) nf = 1.0f;
+    const float lam = __builtin_amdgcn_logf(pmax / nf);
+    const float du = major_x ? g.dudx : g.dudy, dv = major_x ? g.dvdx : g.dvdy;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float np1 = nf + 1.0f;
+    // lanes run their own tap counts (at most 16)
+#pragma unroll 1
+    for (float fi = 1.0f; fi <= nf; fi += 1.0f) {
+        const float ti = fi / np1 - 0.5f;
+        const f4 sm = sample_trilinear(texels, w, h, levels, u + du * ti, v + dv * ti, lam, srgb);
+        acc.x += sm.x; acc.y += sm.y; acc.z += sm.z; acc.w += sm.w;
+    }
+    return {acc.x / nf, acc.y / nf, acc.z / nf, acc.w / nf};
 }
 
 #pragma clang fp contract(off)

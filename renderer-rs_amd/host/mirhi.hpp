@@ -254,6 +254,8 @@ public:
     void upload(const void* src) const { check(mirhi_image_upload(h_, src, mirhi_image_size_bytes(h_))); }
     void generate_mips() const { check(mirhi_image_generate_mips(h_)); }     // texture fidelity
     uint32_t mip_levels() const { return mirhi_image_mip_levels(h_); }
+    void set_max_anisotropy(uint32_t n) { check(mirhi_image_set_max_anisotropy(h_, n)); }          // sampler state (device.rs:161-165)
+    uint32_t max_anisotropy() const { return mirhi_image_max_anisotropy(h_); }
 private:
     std::shared_ptr<Device> device_;
     mirhi_image* h_ = nullptr;

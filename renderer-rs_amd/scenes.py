@@ -193,6 +193,7 @@ class Texture:
     rgba8: np.ndarray  # (h, w, 4) uint8
     mips: bool = False  # sampled trilinearly through a full mip chain (mirhi_image_generate_mips / mip_chain below)
     srgb: bool = False  # R8G8B8A8_SRGB: the RGB bytes are decoded to linear when sampled
+    max_anisotropy: int = 1  # > 1 (at most 16, needs mips): anisotropic filtering (mirhi_image_set_max_anisotropy)
 
     @property
     def width(self):
@@ -697,10 +698,11 @@ def pbr_spheres_case(width: int = 224, height: int = 144) -> Scene:
     return Scene("pbr-spheres", width, height, draws, clear_color=(0.02, 0.02, 0.03, 1.0))
 
 
-def mip_ground_case(width: int = 240, height: int = 150) -> Scene:
+def mip_ground_case(width: int = 240, height: int = 150, max_anisotropy: int = 1) -> Scene:
     """Texture fidelity: a ground plane receding to the horizon under a fine checker -- strong, anisotropic
     minification -- through a mip chain with trilinear filtering and an sRGB-encoded albedo, plus an upright quad that is
-    magnified (lambda clamps to 0).  A non-power-of-two normal map exercises the odd-size rule of the chain."""
+    magnified (lambda clamps to 0).  A non-power-of-two normal map exercises the odd-size rule of the chain.
+    max_anisotropy > 1: the same frame through the anisotropic filter (albedo at max_anisotropy, normal map at a quarter of it)."""
     rng = PCG32(0x717)
     n = 64
     yy, xx = np.mgrid[0:n, 0:n]
@@ -711,7 +713,8 @@ def mip_ground_case(width: int = 240, height: int = 150) -> Scene:
     r = rng.uniform(24 * 40 * 2).reshape(24, 40, 2)
     nm[..., 0] = (128 + (r[..., 0] - 0.5) * 70).astype(np.uint8); nm[..., 1] = (128 + (r[..., 1] - 0.5) * 70).astype(np.uint8)
     nm[..., 2] = 235; nm[..., 3] = 255
-    albedo, normal = Texture(alb, mips=True, srgb=True), Texture(nm, mips=True)
+    albedo = Texture(alb, mips=True, srgb=True, max_anisotropy=max_anisotropy)
+    normal = Texture(nm, mips=True, max_anisotropy=max(1, max_anisotropy // 4))
     view, proj, cam = default_camera(width, height, eye=(0.0, 1.2, 4.0), target=(0.0, 0.3, 0.0))
     light = light_ubo(direction=(0.2, -1.0, -0.3), intensity=0.9, color=(1.0, 0.97, 0.9), num_point=1)
     points = point_light((1.0, 2.0, 1.5), 12.0, (0.8, 0.9, 1.0), 5.0)
@@ -725,7 +728,7 @@ def mip_ground_case(width: int = 240, height: int = 150) -> Scene:
     common = dict(stride=48, count=6, indices=idx, program=PROGRAM_MODEL_FULL, cull_mode=CULL_NONE, camera=cam,
                   object=object_ubo(np.eye(4, dtype=f32)), light=light, point_lights=points,
                   material=material_ubo((1.0, 1.0, 1.0, 1.0), 0.0, 0.6, 0.9), albedo_map=albedo, normal_map=normal)
-    return Scene("mip-ground", width, height, [DrawSpec(vertices=ground, **common), DrawSpec(vertices=wall, **common)],
+    return Scene("mip-ground" if max_anisotropy <= 1 else f"aniso{max_anisotropy}-ground", width, height, [DrawSpec(vertices=ground, **common), DrawSpec(vertices=wall, **common)],
                  clear_color=(0.3, 0.5, 0.8, 1.0))
 
 
@@ -793,6 +796,7 @@ SMALL_CASES = {
     "textured": textured_quad_case,
     "pbr": pbr_spheres_case,
     "mips": mip_ground_case,
+    "aniso": lambda: mip_ground_case(max_anisotropy=16),
     "random_small": lambda: random_triangles(300, 320, 200, seed=42, rmin=2, rmax=40),
     "sphere_small": lambda: displaced_sphere(24, 17, 256, 160, seed=3),
 }

@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(ORACLE_DIR, "libmirhi_oracle.so")
 
 
 class OracleTexture(C.Structure):
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32), ("srgb", C.c_uint32)]
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("levels", C.c_uint32), ("srgb", C.c_uint32),
+                ("max_anisotropy", C.c_uint32)]
 
 
 class OracleDraw(C.Structure):
@@ -133,7 +134,8 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
                     levels = len(chain)
                     arr = np.concatenate([l.reshape(-1) for l in chain])
                 keep.append(arr)
-                t = OracleTexture(arr.ctypes.data, tex.width, tex.height, levels, int(getattr(tex, "srgb", False)))
+                t = OracleTexture(arr.ctypes.data, tex.width, tex.height, levels, int(getattr(tex, "srgb", False)),
+                                  int(getattr(tex, "max_anisotropy", 1)))
                 setattr(od, name, t)
     p = OraclePass()
     p.width, p.height = scene.width, scene.height

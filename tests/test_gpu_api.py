@@ -780,3 +780,23 @@ def test_indirect_draws_and_push_constants(mirhi, oracle, device, scenes):
     cmd.end_rendering(); cmd.end()
     for o in (cmd, ind, vb, pipe, prim, color):
         o.destroy()
+
+
+def test_max_anisotropy_is_sampler_state_of_a_texture(mirhi, device):
+    """mirhi_image_set_max_anisotropy: default 1, [1, 16] accepted (maxSamplerAnisotropy), refused on anything but a sampled
+    R8G8B8A8 texture (device.rs:161-165 enables the feature; sampler.rs is a stub)."""
+    t = mirhi.Image(device, 8, 8, mirhi.Format.R8G8B8A8_SRGB)
+    assert t.max_anisotropy == 1
+    t.set_max_anisotropy(16)
+    assert t.max_anisotropy == 16
+    for bad in (0, 17, 1 << 20):
+        with pytest.raises(mirhi.RhiError) as e:
+            t.set_max_anisotropy(bad)
+        assert "maxAnisotropy" in str(e.value)
+    assert t.max_anisotropy == 16
+    target = mirhi.Image(device, 8, 8, mirhi.Format.B8G8R8A8_SRGB)
+    with pytest.raises(mirhi.RhiError) as e:
+        target.set_max_anisotropy(4)
+    assert "Invalid handle" in str(e.value)
+    target.destroy()
+    t.destroy()

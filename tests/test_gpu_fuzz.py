@@ -112,7 +112,8 @@ def _random_pbr_scene(scenes, seed):
 
     def tex(n):        # square or not, a third with a mip chain (trilinear), a third sRGB-encoded
         return scenes.Texture(rng.integers(0, 256, (n, int(rng.integers(1, 24)) if rng.random() < 0.3 else n, 4), dtype=np.uint8),
-                              mips=bool(rng.random() < 0.35), srgb=bool(rng.random() < 0.35))
+                              mips=bool(rng.random() < 0.35), srgb=bool(rng.random() < 0.35),
+                              max_anisotropy=int(rng.choice([1, 1, 2, 4, 7, 16])))
 
     eye = (float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-0.8, 0.8)), float(rng.uniform(1.2, 4.0)))
     view = scenes.look_at_rh(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))

@@ -43,14 +43,14 @@ def _check(out, ref, name, depth=False):
 
 
 @pytest.mark.parametrize("case", ["hello", "fan", "near_clip", "depth_tie", "cull_scissor", "multi_draw", "huge",
-                                  "textured", "pbr", "mips", "random_small", "sphere_small"])
+                                  "textured", "pbr", "mips", "aniso", "random_small", "sphere_small"])
 def test_small_cases_float(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, want_depth=any(d.depth_test for d in scene.draws))
     _check(out, ref, scene.name, depth=any(d.depth_test for d in scene.draws))
 
 
-@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr", "mips"])
+@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr", "mips", "aniso"])
 def test_small_cases_srgb8(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, fmt=mirhi.Format.B8G8R8A8_SRGB)
@@ -461,3 +461,53 @@ def test_full_size_eight_way_tile_row_split_equals_the_unsplit_frame(mirhi, scen
     target.destroy()
     dev.set_tile_split(0, 1)
     dev.destroy()
+
+
+def _k9_quad(scenes, tex, W, H, su, sv):
+    """The oracle KATs' viewport-filling textured quad (tests/test_oracle_kats.py K8 / K9) with separate uv scales."""
+    pos = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=np.float32)
+    verts = np.zeros((4, 12), dtype=np.float32)
+    verts[:, 0:3] = pos; verts[:, 3:6] = [0, 0, 1]; verts[:, 8:12] = [1, 0, 0, 1]
+    verts[:, 6:8] = np.array([[0, 0], [su, 0], [su, sv], [0, sv]], dtype=np.float32)
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    ident = np.eye(4, dtype=np.float32)
+    d = scenes.DrawSpec(vertices=verts, stride=48, count=6, indices=idx, program=scenes.PROGRAM_MODEL_FULL,
+                        cull_mode=scenes.CULL_NONE, depth_test=False, depth_write=False,
+                        camera=scenes.camera_ubo(ident, ident, (0.0, 0.0, 1.0)), object=scenes.object_ubo(ident),
+                        light=scenes.light_ubo(intensity=0.0), material=scenes.material_ubo((1.0, 1.0, 1.0, 1.0), 0.0, 1.0, 1.0),
+                        albedo_map=tex, normal_map=scenes.WHITE_1X1)
+    return scenes.Scene("k9", W, H, [d])
+
+
+@pytest.mark.parametrize("max_aniso,resolved", [(1, False), (4, False), (8, True), (16, True)])
+def test_anisotropic_filter_kat(mirhi, oracle, device, scenes, max_aniso, resolved):
+    """K9 on the HIP path: 8 texels per pixel along x, 1 along y, 1-texel stripes along y.  Trilinear (and N < 8) blurs them to
+    grey; N = 8 taps along x at level 0 keep them -- and the image equals the oracle's within the float tolerance."""
+    n = W = H = 64
+    yy, _ = np.mgrid[0:n, 0:n]
+    tex = np.zeros((n, n, 4), dtype=np.uint8)
+    tex[..., 0:3] = (255 * (yy & 1))[..., None]
+    tex[..., 3] = 255
+    scene = _k9_quad(scenes, scenes.Texture(tex, mips=True, max_anisotropy=max_aniso), W, H, 8.0, 1.0)
+    out, ref = _render_both(mirhi, oracle, device, scene)
+    _check(out, ref, f"k9-aniso{max_aniso}")
+    lum = out["color"][8:56, 8:56, 0] / 0.03
+    if resolved:
+        assert lum.min() < 1e-4 and lum.max() > 0.9999
+    else:
+        assert np.allclose(lum, 128.0 / 255.0, atol=1e-4)
+
+
+def test_anisotropic_filter_isotropic_footprint_is_trilinear(mirhi, device, scenes):
+    """N = ceil(Pmax / Pmin) = 1 on an isotropic footprint: one tap at the centre at the trilinear lambda -- the frame is the
+    trilinear frame bit for bit, whatever max_anisotropy allows (the N the HIP path computes is an exact integer, not an estimate)."""
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    frames = []
+    for a in (1, 16):
+        res = mirhi.SceneResources(device, _k9_quad(scenes, scenes.Texture(noise, mips=True, max_anisotropy=a), 96, 96, 3.0, 3.0),
+                                   mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+        res.render()
+        frames.append(res.read()["color"].copy())
+        res.destroy()
+    assert np.array_equal(frames[0], frames[1])

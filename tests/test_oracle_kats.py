@@ -344,3 +344,89 @@ def test_k8_srgb_decode(oracle, scenes):
         c = byte / 255.0
         want = c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
         assert got == pytest.approx(want, rel=2e-6, abs=1e-8), byte
+
+
+# ------------------------------------------------------------------------------------------------
+# K9: anisotropic filtering (the Vulkan specification's example filter) against closed forms
+# ------------------------------------------------------------------------------------------------
+def _stripe_texture(scenes, n, along_v, max_anisotropy):
+    """1-texel stripes that vary along v (along_v) or along u: every 2x2 block averages to the same grey from level 1 on."""
+    yy, xx = np.mgrid[0:n, 0:n]
+    tex = np.zeros((n, n, 4), dtype=np.uint8)
+    tex[..., 0:3] = (255 * ((yy if along_v else xx) & 1))[..., None]
+    tex[..., 3] = 255
+    return scenes.Texture(tex, mips=True, max_anisotropy=max_anisotropy)
+
+
+def _aniso_quad(scenes, tex, W, H, su, sv):
+    """The K8 quad with separate uv scales: su * n / W texels per pixel along x, sv * n / H along y."""
+    sc = _textured_quad_scene(scenes, tex, W, H, 1.0)
+    v = sc.draws[0].vertices
+    v[:, 6] *= su
+    v[:, 7] *= sv
+    return sc
+
+
+@pytest.mark.parametrize("max_aniso,resolved", [(1, False), (2, False), (4, False), (8, True), (16, True)])
+def test_k9_taps_follow_the_long_axis_and_lod_drops_by_log2_n(oracle, scenes, max_aniso, resolved):
+    """8 texels per pixel along x, 1 along y, stripes that vary along y only.  Trilinear: lambda = log2(8) = 3, the stripes are
+    gone (grey 128/255).  Anisotropic: N = min(ceil(8 / 1), max) taps along x at lambda = log2(8 / N): with N = 8 that is level 0,
+    and taps displaced along x leave the stripes untouched; with N = 2 or 4 lambda is 2 or 1, still grey."""
+    n = W = H = 64
+    sc = _aniso_quad(scenes, _stripe_texture(scenes, n, True, max_aniso), W, H, 8.0, 1.0)
+    out = oracle.render(sc)["rgba"][8:56, 8:56, 0] / 0.03
+    if resolved:
+        # the pixel centres sit on texel centres along v (1 texel per pixel): the bilinear tap returns the texel itself
+        assert set(np.round(out.reshape(-1), 4)) == {0.0, 1.0}
+        assert np.array_equal(out[:, 0] > 0.5, (np.arange(8, 56) & 1).astype(bool))
+    else:
+        assert np.allclose(out, 128.0 / 255.0, atol=1e-5)
+
+
+def test_k9_major_axis_y_and_isotropic_footprint(oracle, scenes):
+    """The same with the axes exchanged (taps along y), and an isotropic footprint: N = ceil(1) = 1 tap at the centre at the
+    trilinear lambda, whatever max_anisotropy allows -- the image equals the trilinear one bit for bit."""
+    n = W = H = 64
+    sc = _aniso_quad(scenes, _stripe_texture(scenes, n, False, 16), W, H, 1.0, 8.0)
+    out = oracle.render(sc)["rgba"][8:56, 8:56, 0] / 0.03
+    assert set(np.round(out.reshape(-1), 4)) == {0.0, 1.0}
+    assert np.array_equal(out[0, :] > 0.5, (np.arange(8, 56) & 1).astype(bool))
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, (n, n, 4), dtype=np.uint8)
+    a = oracle.render(_aniso_quad(scenes, scenes.Texture(noise, mips=True, max_anisotropy=16), W, H, 3.0, 3.0))["rgba"]
+    b = oracle.render(_aniso_quad(scenes, scenes.Texture(noise, mips=True, max_anisotropy=1), W, H, 3.0, 3.0))["rgba"]
+    assert np.array_equal(a, b)
+
+
+def test_k9_mean_of_taps_closed_form(oracle, scenes):
+    """Taps displaced along the long axis (y) over a texture that varies along x only all return the value at the centre, so
+    the image is the trilinear lookup of that texture at the anisotropic lambda = log2(Pmax / N) -- which differs from the
+    isotropic one (log2(Pmax)) -- checked against float64 arithmetic.  Level 0 holds floor(x / 2), level 1 its exact 2x2 means."""
+    n, W, H = 256, 64, 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    tex = np.zeros((n, n, 4), dtype=np.uint8)
+    tex[..., 0:3] = (xx // 2)[..., None]           # value = floor(x / 2): level l holds floor(x_l * 2^l / 2) for l >= 1 exactly
+    tex[..., 3] = 255
+    # 1.5 texels per pixel along x (the short axis), 6 along y: N = ceil(6 / 1.5) = 4, lambda = log2(6 / 4)
+    sc = _aniso_quad(scenes, scenes.Texture(tex, mips=True, max_anisotropy=16), W, H, 1.5 * W / n, 6.0 * H / n)
+    out = oracle.render(sc)["rgba"][:, :, 0].astype(np.float64) / 0.03
+    lam = np.log2(6.0 / 4.0)
+    f = lam                                        # between level 0 and level 1
+    for px in (10, 20, 33, 50):
+        u = (px + 0.5) / W * (1.5 * W / n)         # uv at the pixel centre
+        def level_value(l):                        # bilinear lookup of the ramp on level l (texel k holds floor(k * 2^l / 2) for l >= 1, k // 2 on level 0)
+            size = n >> l
+            fx = u * size - 0.5
+            x0 = int(np.floor(fx)); a = fx - x0
+            val = (lambda k: (k // 2) if l == 0 else k * (1 << l) // 2)
+            return ((1 - a) * val(x0) + a * val(x0 + 1)) / 255.0
+        want = (1 - f) * level_value(0) + f * level_value(1)
+        assert out[30, px] == pytest.approx(want, abs=2e-6), px
+
+
+def test_k9_binding_default_is_trilinear(oracle, scenes):
+    sc = scenes.SMALL_CASES["mips"]()
+    assert all(d.albedo_map.max_anisotropy == 1 for d in sc.draws)
+    assert scenes.SMALL_CASES["aniso"]().draws[0].albedo_map.max_anisotropy == 16
+    a, b = oracle.render(sc)["rgba"], oracle.render(scenes.SMALL_CASES["aniso"]())["rgba"]
+    assert not np.array_equal(a, b)                # the receding ground is where the two filters differ
