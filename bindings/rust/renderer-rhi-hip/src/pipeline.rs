@@ -105,6 +105,8 @@ impl GraphicsPipelineBuilder {
     pub fn depth_test_enable(mut self, on: bool) -> Self { self.desc.depth_test_enable = on as u32; self }
     pub fn depth_write_enable(mut self, on: bool) -> Self { self.desc.depth_write_enable = on as u32; self }
     pub fn depth_compare_op(mut self, op: CompareOp) -> Self { self.desc.depth_compare_op = op as i32; self }
+    /// Alpha-masked MODEL_PBR materials (`discard`, model_pbr.hlsl:176-179): fragments are resolved one by one in primitive order.
+    pub fn fragment_discard_enable(mut self, on: bool) -> Self { self.desc.fragment_discard_enable = on as u32; self }
     pub fn color_attachment_format(mut self, f: Format) -> Self {
         self.desc.color_attachment_count = 1; self.desc.color_attachment_formats[0] = f as i32; self
     }

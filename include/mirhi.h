@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MIRHI_ABI_VERSION 2u
+#define MIRHI_ABI_VERSION 3u     /* 3: mirhi_pipeline_desc.fragment_discard_enable */
 
 /* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
 typedef int32_t mirhi_result;
@@ -181,6 +181,12 @@ typedef struct {
     int32_t  src_color_blend_factor, dst_color_blend_factor, color_blend_op;
     int32_t  src_alpha_blend_factor, dst_alpha_blend_factor, alpha_blend_op;
     uint32_t color_write_mask;          /* bit 0 R, 1 G, 2 B, 3 A */
+    /* default 0.  The MODEL_PBR fragment program ends fragments whose base-colour alpha is below the material's alphaCutoff
+     * (`discard`, pixel/model_pbr.hlsl:176-179).  With a base colour texture that is a decision per fragment, taken before the depth
+     * write: pipelines for alpha-masked materials (glTF alphaMode MASK) set this, and their draws are resolved fragment by fragment
+     * in primitive order like blended ones (DESIGN.md "Ordered segments").  Without it such a draw is refused loudly at the fence
+     * ("alpha cutoff"); draws whose alpha cannot cross the cutoff (no texture, or cutoff <= 0) never need it. */
+    uint32_t fragment_discard_enable;
 } mirhi_pipeline_desc;
 void         mirhi_pipeline_desc_default(mirhi_pipeline_desc* desc);                      /* GraphicsPipelineBuilder::new :645-698 */
 mirhi_result mirhi_pipeline_create(mirhi_device* dev, const mirhi_pipeline_desc* desc, mirhi_pipeline** out); /* build :918-1057 */
@@ -242,6 +248,8 @@ mirhi_result mirhi_cmd_bind_uniform(mirhi_cmd* cmd, mirhi_uniform_slot slot, mir
 mirhi_result mirhi_cmd_bind_texture(mirhi_cmd* cmd, mirhi_texture_slot slot, mirhi_image* image);   /* descriptor.rs:411-420 image_info */
 mirhi_result mirhi_cmd_set_viewport(mirhi_cmd* cmd, const mirhi_viewport* viewport);  /* set_viewport :522 */
 mirhi_result mirhi_cmd_set_scissor(mirhi_cmd* cmd, const mirhi_rect2d* scissor);      /* set_scissor :549 */
+/* instance_count > 1 (at most 4096): the path has no instance-rate input (binding 0 is per-vertex, vertex.rs:35-41,130-136; no program
+ * reads SV_InstanceID), so instance i draws the same primitives again behind instance i - 1; first_instance has nothing to offset. */
 mirhi_result mirhi_cmd_draw(mirhi_cmd* cmd, uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance); /* draw :583 */
 mirhi_result mirhi_cmd_draw_indexed(mirhi_cmd* cmd, uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance); /* draw_indexed :610 */
 

@@ -722,6 +722,7 @@ typedef struct {
     float* out_rgba; uint8_t* out_bgra8;
     float* blend_color;         /* width*height*4, only when some draw blends: the pixel's current colour */
     uint8_t* blend_valid;       /* 1 = blend_color holds the pixel's colour; 0 = it is still the shade of prim[idx] (or the clear colour) */
+    const uint8_t* alpha_test;  /* per draw: 1 = the draw's fragments are discarded one by one (model_pbr.hlsl:176-179 with a base colour texture) */
 } band_job;
 
 /* ------------------------------------------------------------------------------------------------
@@ -792,6 +793,15 @@ static void* band_run(void* arg) {
                 size_t idx = (size_t)y * W + (size_t)x;
                 int pass_test = d->depth_test ? depth_cmp(d->depth_compare, z, j->depth[idx]) : 1;
                 if (!pass_test) continue;
+                float src[4];
+                int have_src = 0;
+                if (j->alpha_test[t->draw]) {
+                    /* `if (baseColor.a < alphaCutoff) discard;` (pixel/model_pbr.hlsl:176-179): the fragment program runs, and a discarded
+                     * fragment writes neither colour nor depth.  The program's alpha output is baseColor.a (:316-320 of this restatement). */
+                    shade_pixel(pass, d, t->prim - j->prim_base[t->draw], (uint32_t)x, (uint32_t)y, src);
+                    have_src = 1;
+                    if (src[3] < rdf(d->material, 44)) continue;
+                }
                 if (d->blend_enable) {
                     /* the destination colour is needed now: resolve what the pixel shows so far, shade this fragment, blend */
                     float* dst = j->blend_color + 4 * idx;
@@ -805,8 +815,7 @@ static void* band_run(void* arg) {
                         }
                         j->blend_valid[idx] = 1;
                     }
-                    float src[4];
-                    shade_pixel(pass, d, t->prim - j->prim_base[t->draw], (uint32_t)x, (uint32_t)y, src);
+                    if (!have_src) shade_pixel(pass, d, t->prim - j->prim_base[t->draw], (uint32_t)x, (uint32_t)y, src);
                     blend_pixel(d, src, dst);
                 } else if (j->blend_valid) {
                     j->blend_valid[idx] = 0;         /* opaque overwrite: the pixel is the shade of this primitive again */
@@ -848,6 +857,7 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
     const size_t npix = (size_t)pass->width * pass->height;
     tri_list tris = {0, 0, 0};
     uint32_t* prim_base = (uint32_t*)calloc(pass->num_draws + 1u, sizeof(uint32_t));
+    uint8_t* alpha_test = (uint8_t*)calloc(pass->num_draws + 1u, 1);
     /* geometry: a1-a5 in submission order */
     uint32_t base = 0;
     for (uint32_t di = 0; di < pass->num_draws; di++) {
@@ -856,15 +866,14 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
         uint32_t ntri = d->count / 3u;                            /* TriangleList (pipeline.rs:655) */
         int dropped = 0;
         if (d->program == ORACLE_PROGRAM_MODEL_PBR) {
-            /* pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` -- restated where one decision
-             * covers the whole draw: alpha = baseColorFactor.a, or texel alpha in [0,1] times it.  A draw whose
-             * texels could fall on both sides of the cutoff needs a per-fragment discard before the depth write;
-             * that is outside this restatement (and the HIP path): report it instead of rendering it wrong. */
+            /* pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;`: alpha = baseColorFactor.a, or texel alpha in
+             * [0,1] times it.  Where one decision covers the whole draw it is taken here (the draw is dropped, or no fragment can be
+             * discarded); a draw whose texels could fall on both sides of the cutoff is discarded fragment by fragment in band_run. */
             float fa = rdf(d->material, 12), cutoff = rdf(d->material, 44);
             float lo = fa, hi = fa;
             if (rdu(d->material, 48) != 0) { lo = fa < 0.0f ? fa : 0.0f; hi = fa > 0.0f ? fa : 0.0f; }
             if (hi < cutoff) dropped = 1;
-            else if (!(lo >= cutoff)) { free(prim_base); free(tris.v); return 2; }
+            else if (!(lo >= cutoff)) alpha_test[di] = 1;
         }
         for (uint32_t t = 0; t < ntri && !dropped; t++) {
             v4 c[3];
@@ -900,7 +909,7 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
         j->row0 = r0 + (uint32_t)(((uint64_t)rows * (uint64_t)i) / (uint64_t)nthreads);
         j->row1 = r0 + (uint32_t)(((uint64_t)rows * (uint64_t)(i + 1)) / (uint64_t)nthreads);
         j->depth = depth; j->prim = prim; j->out_rgba = out_rgba; j->out_bgra8 = out_bgra8;
-        j->blend_color = blend_color; j->blend_valid = blend_valid;
+        j->blend_color = blend_color; j->blend_valid = blend_valid; j->alpha_test = alpha_test;
         if (nthreads == 1) band_run(j);
         else pthread_create(&th[i], NULL, band_run, j);
     }
@@ -909,7 +918,7 @@ int oracle_render(const oracle_pass* pass, int nthreads, float* out_rgba, uint32
     free(blend_color); free(blend_valid);
     if (!out_depth) free(depth);
     if (!out_prim) free(prim);
-    free(prim_base);
+    free(prim_base); free(alpha_test);
     free(tris.v);
     return 0;
 }

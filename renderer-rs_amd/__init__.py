@@ -122,6 +122,7 @@ class PipelineDesc(C.Structure):
         ("src_color_blend_factor", C.c_int32), ("dst_color_blend_factor", C.c_int32), ("color_blend_op", C.c_int32),
         ("src_alpha_blend_factor", C.c_int32), ("dst_alpha_blend_factor", C.c_int32), ("alpha_blend_op", C.c_int32),
         ("color_write_mask", C.c_uint32),
+        ("fragment_discard_enable", C.c_uint32),
     ]
 
 
@@ -513,6 +514,11 @@ class GraphicsPipelineBuilder:
         self.desc.blend_enable = int(e)
         return self
 
+    def fragment_discard_enable(self, e: bool):
+        """Pipelines of alpha-masked MODEL_PBR materials (model_pbr.hlsl:176-179 `discard`): per-fragment, ordered resolve."""
+        self.desc.fragment_discard_enable = int(e)
+        return self
+
     def color_blend_attachment(self, src_color, dst_color, color_op, src_alpha, dst_alpha, alpha_op, write_mask=0xF):
         """ColorBlendAttachment (pipeline.rs:478-531) with blending enabled."""
         d = self.desc
@@ -765,6 +771,8 @@ class SceneResources:
                 b.depth_attachment_format(Format.D32_SFLOAT)
             if getattr(d, "blend", None) is not None:
                 b.color_blend_attachment(*d.blend)
+            if getattr(d, "alpha_test", False):
+                b.fragment_discard_enable(True)
             pipe = b.build(device)
             self.objs.append(pipe)
             st = dict(pipe=pipe, vb=buf(BufferUsage.Vertex, d.vertices),
@@ -801,9 +809,9 @@ class SceneResources:
                     cmd.bind_texture(slot, img)
             if st["ib"] is not None:
                 cmd.bind_index_buffer(st["ib"], 0, IndexType.UINT16 if d.index_type == 2 else IndexType.UINT32)
-                cmd.draw_indexed(d.count, 1, d.first, d.vertex_offset, 0)
+                cmd.draw_indexed(d.count, getattr(d, "instances", 1), d.first, d.vertex_offset, 0)
             else:
-                cmd.draw(d.count, 1, d.first, 0)
+                cmd.draw(d.count, getattr(d, "instances", 1), d.first, 0)
         cmd.end_rendering()
         cmd.end()
 

@@ -142,7 +142,7 @@ struct RecordedPass {
     std::vector<uint64_t> draw_vb_bytes;   // bytes of the bound vertex buffer range per draw (vertex pre-pass extent)
     uint32_t total_tris = 0;
     bool key_set = false;
-    uint32_t depth_test = 0, depth_compare = 0, depth_write = 0;
+    uint32_t depth_test = 0, depth_compare = 0, depth_write = 0, frag_discard = 0;
     uint32_t blend[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
     // a scope whose pipelines change the depth state is continued in a new segment: colour is kept (LOAD), depth is
     // carried through the depth attachment or, without one, a transient buffer of the workspace
@@ -864,7 +864,16 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
     if (!cmd->vb) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: no vertex buffer bound to binding 0");
     if (indexed && !cmd->ib) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: no index buffer bound");
     if (!cmd->has_viewport || !cmd->has_scissor) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: viewport and scissor are dynamic state and must be set before drawing (pipeline.rs:697)");
-    if (instance_count > 1) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: instance_count %u (1 supported)", instance_count);
+    if (instance_count > 1) {
+        // The path has no instance-rate input (binding 0 is per-vertex, vertex.rs:35-41,130-136; no program reads SV_InstanceID): instance i
+        // rasterizes the same triangles again, behind instance i - 1 in primitive order -- recorded as that many draws of one instance.
+        if (instance_count > 4096u) return fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: instance_count %u (at most 4096 per draw)", instance_count);
+        for (uint32_t inst = 0; inst < instance_count; inst++) {
+            const mirhi_result ri = record_draw(cmd, indexed, count, 1u, first, vertex_offset);
+            if (ri != MIRHI_OK) return ri;
+        }
+        return MIRHI_OK;
+    }
     const mirhi_pipeline_desc& pd = cmd->pipeline->desc;
     const mirhi_image* ci = cmd->passes.back().info.color_image;
     if (pd.color_attachment_formats[0] != (int32_t)ci->format)
@@ -883,12 +892,13 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
         blend[4] = (uint32_t)pd.src_alpha_blend_factor; blend[5] = (uint32_t)pd.dst_alpha_blend_factor; blend[6] = (uint32_t)pd.alpha_blend_op;
         blend[7] = pd.color_write_mask & 0xFu;
     }
+    const uint32_t discard = pd.fragment_discard_enable ? 1u : 0u;
     if (!cmd->passes.back().key_set) {
         RecordedPass& p0 = cmd->passes.back();
-        p0.key_set = true; p0.depth_test = dtest; p0.depth_compare = dcmp; p0.depth_write = dwrite;
+        p0.key_set = true; p0.depth_test = dtest; p0.depth_compare = dcmp; p0.depth_write = dwrite; p0.frag_discard = discard;
         memcpy(p0.blend, blend, sizeof blend);
     } else if (cmd->passes.back().depth_test != dtest || cmd->passes.back().depth_compare != dcmp || cmd->passes.back().depth_write != dwrite ||
-               memcmp(cmd->passes.back().blend, blend, sizeof blend) != 0) {
+               cmd->passes.back().frag_discard != discard || memcmp(cmd->passes.back().blend, blend, sizeof blend) != 0) {
         // One raster launch resolves one depth state (DESIGN.md "Depth key"): the scope continues in a new segment that
         // loads what the previous one stored -- fragments keep their submission order across the cut.
         RecordedPass next;
@@ -901,7 +911,7 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
             next.carry_in = true;
             next.first_tri = next.total_tris = prev.total_tris;
         }
-        next.key_set = true; next.depth_test = dtest; next.depth_compare = dcmp; next.depth_write = dwrite;
+        next.key_set = true; next.depth_test = dtest; next.depth_compare = dcmp; next.depth_write = dwrite; next.frag_discard = discard;
         memcpy(next.blend, blend, sizeof blend);
         cmd->passes.push_back(std::move(next));
     }
@@ -1042,10 +1052,11 @@ static mirhi_result grow(T** ptr, size_t* have, size_t want_bytes) {
     return MIRHI_OK;
 }
 
-// A segment is resolved fragment by fragment in primitive order (ordered_kernel) when its colour is blended, or when its
-// depth state makes the stored depth depend on the order of all fragments (NotEqual with depth write).
+// A segment is resolved fragment by fragment in primitive order (ordered_kernel) when its colour is blended, when its
+// depth state makes the stored depth depend on the order of all fragments (NotEqual with depth write), or when its fragment
+// program may discard single fragments (mirhi_pipeline_desc::fragment_discard_enable: visibility then needs the program's result).
 static bool pass_is_ordered(const RecordedPass& pass) {
-    return pass.key_set && (pass.blend[0] != 0 || (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL));
+    return pass.key_set && (pass.blend[0] != 0 || pass.frag_discard != 0 || (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL));
 }
 
 static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
@@ -1568,7 +1579,7 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
         if (c->ws.status_host[0] & STATUS_PAGE_TIMEOUT)
             r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer bin page was never published; frame is incomplete");
         if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
-            r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: unsupported: MODEL_PBR alpha cutoff together with a base colour texture (per-fragment discard); that draw was skipped");
+            r = fail(MIRHI_ERR_PIPELINE, "Pipeline error: MODEL_PBR alpha cutoff together with a base colour texture needs a per-fragment discard: set mirhi_pipeline_desc.fragment_discard_enable on that pipeline; the draw was skipped");
         if (c->ws.status_host[0] & STATUS_BIG_OVERFLOW)
             r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer large-triangle list overflowed (%u entries); frame is incomplete", c->ws.status_host[1]);
     }

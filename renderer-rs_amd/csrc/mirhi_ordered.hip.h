@@ -94,7 +94,11 @@ __device__ __forceinline__ void ordered_record(const RecRegs& r, uint32_t box, i
             else if (PROGS == 2) src = shade_model_program<false>(D, tri, pxc, pyc);
             else src = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program<PROGS == 4>(D, tri, pxc, pyc);
         }
-        if (pass) {
+        // `if (baseColor.a < alphaCutoff) discard;` (pixel/model_pbr.hlsl:176-179; the program's alpha output is baseColor.a): a discarded
+        // fragment writes neither colour nor depth nor its primitive id
+        bool kept = pass;
+        if (PROGS == 4 && D.program == 3 && src.w < ldcf(cb(D.material), 44)) kept = false;
+        if (kept) {
             const f4 dcol = {__uint_as_float(ORD_STATE(2u, b)), __uint_as_float(ORD_STATE(3u, b)), __uint_as_float(ORD_STATE(4u, b)), __uint_as_float(ORD_STATE(5u, b))};
             const f4 out = blend_pixel(P, src, dcol);
             ORD_STATE(2u, b) = __float_as_uint(out.x); ORD_STATE(3u, b) = __float_as_uint(out.y);

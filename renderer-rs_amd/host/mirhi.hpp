@@ -329,6 +329,7 @@ public:
     GraphicsPipelineBuilder& depth_test_enable(bool e) { d_.depth_test_enable = e; return *this; }
     GraphicsPipelineBuilder& depth_write_enable(bool e) { d_.depth_write_enable = e; return *this; }
     GraphicsPipelineBuilder& depth_compare_op(CompareOp op) { d_.depth_compare_op = (int32_t)op; return *this; }
+    GraphicsPipelineBuilder& fragment_discard_enable(bool e) { d_.fragment_discard_enable = e; return *this; }   // alpha-masked MODEL_PBR materials (model_pbr.hlsl:176-179)
     GraphicsPipelineBuilder& color_blend_attachment(const ColorBlendAttachment& a) {      // pipeline.rs color_blend_attachments
         d_.blend_enable = a.blend_enable ? 1u : 0u;
         d_.src_color_blend_factor = (int32_t)a.src_color_blend_factor; d_.dst_color_blend_factor = (int32_t)a.dst_color_blend_factor; d_.color_blend_op = (int32_t)a.color_blend_op;

@@ -246,6 +246,8 @@ class DrawSpec:
     metallic_roughness_map: Optional[Texture] = None   # MODEL_PBR only (model_pbr.hlsl:62-95 t2..t4)
     occlusion_map: Optional[Texture] = None
     emissive_map: Optional[Texture] = None
+    alpha_test: bool = False              # pipeline fragment_discard_enable: alpha-masked MODEL_PBR material (per-fragment discard)
+    instances: int = 1                    # instance_count of the draw call: the same primitives again, instance after instance
     blend: Optional[tuple] = None         # None = opaque; else (src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask)
 
     @property
@@ -260,7 +262,7 @@ class DrawSpec:
 
     @property
     def num_triangles(self) -> int:
-        return self.count // 3
+        return (self.count // 3) * self.instances
 
     def vertex_bytes(self) -> np.ndarray:
         return np.ascontiguousarray(self.vertices).view(np.uint8).reshape(-1)
@@ -656,6 +658,46 @@ def textured_quad_case(width: int = 160, height: int = 120) -> Scene:
     return Scene("textured-quad", width, height, [d], clear_color=(0.0, 0.0, 0.0, 1.0))
 
 
+def alpha_mask_case(width: int = 200, height: int = 140) -> Scene:
+    """Alpha-masked Cook-Torrance materials (`if (baseColor.a < alphaCutoff) discard;`, pixel/model_pbr.hlsl:176-179; glTF alphaMode
+    MASK): an opaque back wall, in front of it a tilted cut-out quad whose texture alpha runs through every value (a fragment is
+    kept or dropped one by one, and a dropped one leaves colour, depth and id to whatever lies behind), a second cut-out that is
+    also alpha-blended, and a masked quad BEHIND the wall (its kept fragments fail the depth test).  The masked pipelines set
+    fragment_discard_enable, so their segments are resolved in primitive order."""
+    rng = PCG32(0xA1FA)
+    view, proj, cam = default_camera(width, height, eye=(0.3, 0.2, 3.4))
+    light = light_ubo(direction=(0.2, -0.6, -0.8), intensity=1.4, color=(1.0, 0.97, 0.92), num_point=1)
+    points = point_light((1.0, 1.5, 2.0), 9.0, (0.6, 0.8, 1.0), 5.0)
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+    leaf = np.zeros((n, n, 4), dtype=np.uint8)
+    leaf[..., 0] = 40 + 3 * xx; leaf[..., 1] = 120 + 4 * yy; leaf[..., 2] = 30; leaf[..., 3] = ((xx * 37 + yy * 91 + (xx * yy) % 7 * 29) % 256).astype(np.uint8)
+    disc = np.zeros((n, n, 4), dtype=np.uint8)
+    rr = np.hypot(xx - 15.5, yy - 15.5)
+    disc[..., 0] = 220; disc[..., 1] = 150 + (r8 := (rng.uniform(n * n).reshape(n, n) * 60).astype(np.uint8)); disc[..., 2] = 60
+    disc[..., 3] = np.clip(255 - rr * 18, 0, 255).astype(np.uint8)
+    wall_tex = _procedural_texture(3, 32, 5)
+    quad = lambda w, h, uvs: _pack_vertex48(np.array([[-w, -h, 0], [w, -h, 0], [w, h, 0], [-w, h, 0]], dtype=f32),
+                                            np.tile(np.array([0, 0, 1], dtype=f32), (4, 1)),
+                                            np.array([[0, 0], [uvs, 0], [uvs, uvs], [0, uvs]], dtype=f32), np.tile(np.array([1, 0, 0, 1], dtype=f32), (4, 1)))
+    idx = np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32)
+    common = dict(stride=48, count=6, indices=idx, program=PROGRAM_MODEL_PBR, cull_mode=CULL_NONE, camera=cam, light=light, point_lights=points)
+    draws = [
+        DrawSpec(vertices=quad(2.2, 1.6, 2.0), object=object_ubo(trs((1, 1, 1), quat_axis_angle((0, 1, 0), 0.15), (0.0, 0.0, -0.8))),
+                 material=pbr_material_ubo((0.9, 0.9, 0.9, 1.0), 0.1, 0.6, 1.0, has_base_color=True), albedo_map=wall_tex, **common),
+        DrawSpec(vertices=quad(1.1, 0.9, 2.5), object=object_ubo(trs((1, 1, 1), quat_axis_angle((0.2, 1, 0.1), 0.7), (-0.5, 0.1, 0.3))),
+                 material=pbr_material_ubo((1.0, 1.0, 1.0, 0.9), 0.0, 0.5, 1.0, alpha_cutoff=0.45, has_base_color=True), albedo_map=Texture(leaf),
+                 alpha_test=True, **common),
+        DrawSpec(vertices=quad(0.8, 0.8, 1.0), object=object_ubo(trs((1, 1, 1), quat_axis_angle((1, 0, 0), -0.4), (0.9, -0.2, 0.6))),
+                 material=pbr_material_ubo((1.0, 1.0, 1.0, 1.0), 0.3, 0.4, 1.0, alpha_cutoff=0.25, has_base_color=True), albedo_map=Texture(disc),
+                 alpha_test=True, blend=ALPHA_BLEND, **common),
+        DrawSpec(vertices=quad(1.5, 1.0, 3.0), object=object_ubo(trs((1, 1, 1), quat_axis_angle((0, 1, 0), 0.0), (0.2, 0.0, -2.0))),
+                 material=pbr_material_ubo((0.2, 0.3, 1.0, 1.0), 0.0, 0.5, 1.0, alpha_cutoff=0.5, has_base_color=True), albedo_map=Texture(leaf),
+                 alpha_test=True, **common),
+    ]
+    return Scene("alpha-mask", width, height, draws, clear_color=(0.05, 0.06, 0.1, 1.0))
+
+
 def pbr_spheres_case(width: int = 224, height: int = 144) -> Scene:
     """Cook-Torrance program (pixel/model_pbr.hlsl): five draws covering every material switch -- factors only,
     all five textures, metallic, a constant-alpha draw the cutoff removes, and a textured draw whose cutoff is
@@ -797,6 +839,7 @@ SMALL_CASES = {
     "pbr": pbr_spheres_case,
     "mips": mip_ground_case,
     "aniso": lambda: mip_ground_case(max_anisotropy=16),
+    "alpha_mask": alpha_mask_case,
     "random_small": lambda: random_triangles(300, 320, 200, seed=42, rmin=2, rmax=40),
     "sphere_small": lambda: displaced_sphere(24, 17, 256, 160, seed=3),
 }

@@ -94,8 +94,11 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
     """Renders a scenes.Scene with the oracle. Returns dict(rgba, prim, depth, bgra8)."""
     L = lib()
     keep = []
-    draws = (OracleDraw * max(1, len(scene.draws)))()
-    for i, d in enumerate(scene.draws):
+    # an instanced draw is its primitives once per instance, in instance order (the path has no per-instance input: command.rs:583-628
+    # passes instance_count through, binding 0 is per-vertex and no program reads SV_InstanceID)
+    expanded = [d for d in scene.draws for _ in range(max(0, int(getattr(d, "instances", 1))))]
+    draws = (OracleDraw * max(1, len(expanded)))()
+    for i, d in enumerate(expanded):
         od = draws[i]
         vb = d.vertex_bytes()
         keep.append(vb)
@@ -141,7 +144,7 @@ def render(scene, nthreads: int = 1, want_bgra8: bool = True, rows=None):
     p.width, p.height = scene.width, scene.height
     p.clear_color = (C.c_float * 4)(*scene.clear_color)
     p.clear_depth = scene.clear_depth
-    p.num_draws = len(scene.draws)
+    p.num_draws = len(expanded)
     p.draws = draws
     if rows is not None:
         p.row_begin, p.row_end = rows

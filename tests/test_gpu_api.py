@@ -359,8 +359,8 @@ def test_pool_grows_after_exhaustion(mirhi, oracle, device, scenes):
 
 def test_pbr_textured_alpha_cutoff_is_reported(mirhi, oracle, device, scenes):
     """pixel/model_pbr.hlsl:174-178: a base-colour texture whose texel alpha could straddle alphaCutoff needs a
-    per-fragment discard, which the path does not do: the fence reports a PipelineError and the draw is skipped
-    (the other draws of the frame are still exact)."""
+    per-fragment discard, which only a pipeline with fragment_discard_enable gets (tests of the `alpha_mask` case): without the
+    flag the fence reports a PipelineError that names it and the draw is skipped (the other draws of the frame are still exact)."""
     sc = scenes.SMALL_CASES["pbr"]()
     sc.draws[4].material = scenes.pbr_material_ubo((0.3, 0.4, 0.9, 0.6), alpha_cutoff=0.25, has_base_color=True)
     res = mirhi.SceneResources(device, sc, want_prim=True)
@@ -369,7 +369,7 @@ def test_pbr_textured_alpha_cutoff_is_reported(mirhi, oracle, device, scenes):
     with pytest.raises(mirhi.RhiError) as e:
         f.wait()
     assert e.value.code == 9   # MIRHI_ERR_PIPELINE
-    assert "alpha cutoff" in e.value.message
+    assert "alpha cutoff" in e.value.message and "fragment_discard_enable" in e.value.message
     out = res.read()
     del sc.draws[4]
     ref = oracle.render(sc, want_bgra8=False)
@@ -800,3 +800,38 @@ def test_max_anisotropy_is_sampler_state_of_a_texture(mirhi, device):
     assert "Invalid handle" in str(e.value)
     target.destroy()
     t.destroy()
+
+
+def test_instanced_draws_repeat_their_primitives_in_instance_order(mirhi, oracle, device, scenes):
+    """draw(vertex_count, instance_count) (command.rs:583-599): no program reads an instance index and binding 0 is per-vertex, so
+    instance i is the same primitives again.  Under additive blending every instance adds once more; under LESS the first instance
+    keeps the pixel (its primitive ids win); the oracle sees the draw once per instance."""
+    sc = scenes.random_triangles(40, 200, 120, seed=77, rmin=6, rmax=40)
+    d = sc.draws[0]
+    d.instances = 3
+    out_less = _both(mirhi, oracle, device, sc)
+    assert out_less[0]["prim"][out_less[0]["prim"] != 0xFFFFFFFF].max() < 40           # instance 0 holds every covered pixel
+    d.depth_test = False; d.depth_write = False
+    d.blend = (scenes.BF_ONE, scenes.BF_ONE, scenes.BO_ADD, scenes.BF_ONE, scenes.BF_ONE, scenes.BO_ADD, 0xF)
+    out_add = _both(mirhi, oracle, device, sc)
+    covered = out_add[0]["prim"] != 0xFFFFFFFF
+    assert out_add[0]["prim"][covered].min() >= 80                                      # the last instance wrote last
+    assert sc.num_triangles == 120
+    res = mirhi.SceneResources(device, sc)                                              # the stated limit is an error, not a hang
+    d.instances = 5000
+    with pytest.raises(mirhi.RhiError) as e:
+        res.record()
+    assert "instance_count" in str(e.value)
+    res.destroy()
+
+
+def _both(mirhi, oracle, device, scene):
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render()
+    out = res.read()
+    res.destroy()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(out["prim"], ref["prim"])
+    err = np.abs(out["color"][..., :4] - ref["rgba"]) / np.maximum(1.0, np.abs(ref["rgba"]))
+    assert float(err.max()) < 1e-4
+    return out, ref

@@ -155,6 +155,18 @@ def _random_pbr_scene(scenes, seed):
         p = rng.uniform(-1, 1, (n, 1, 2)) + rng.normal(0, 0.2, (n, 3, 2))
         verts = np.concatenate([p, rng.uniform(0, 1, (n, 3, 1)), rng.uniform(0, 1, (n, 3, 3))], axis=2).astype(np.float32).reshape(n * 3, 6)
         draws.append(scenes.DrawSpec(vertices=verts, stride=24, count=3 * n, program=scenes.PROGRAM_TRIANGLE, cull_mode=scenes.CULL_NONE))
+    # a third of the scenes carry an alpha-masked material: a textured draw whose texel alpha straddles the cutoff, drawn by a
+    # pipeline with fragment_discard_enable (per-fragment discard, ordered resolve).  Bilinear textures only: under a mip chain the
+    # level-of-detail comes from v_log_f32 here and log2f in the oracle, and a discard decision has no tolerance.
+    rng2 = np.random.default_rng(seed ^ 0xA17A)
+    masked = [d for d in draws if d.program == scenes.PROGRAM_MODEL_PBR and d.albedo_map is not None and not d.albedo_map.mips
+              and np.frombuffer(d.material, dtype=np.uint32)[12] != 0]
+    if masked and rng2.random() < 0.33:
+        d = masked[int(rng2.integers(0, len(masked)))]
+        mat = np.frombuffer(d.material, dtype=np.float32).copy()
+        mat[11] = mat[3] * float(rng2.uniform(0.2, 0.8))          # alphaCutoff @44 = a fraction of baseColorFactor.a @12
+        d.material = mat.tobytes()
+        d.alpha_test = True
     return scenes.Scene(f"fuzz-pbr-{seed}", W, H, draws, clear_color=tuple(rng.uniform(0, 1, 3)) + (1.0,))
 
 

@@ -43,14 +43,14 @@ def _check(out, ref, name, depth=False):
 
 
 @pytest.mark.parametrize("case", ["hello", "fan", "near_clip", "depth_tie", "cull_scissor", "multi_draw", "huge",
-                                  "textured", "pbr", "mips", "aniso", "random_small", "sphere_small"])
+                                  "textured", "pbr", "mips", "aniso", "alpha_mask", "random_small", "sphere_small"])
 def test_small_cases_float(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, want_depth=any(d.depth_test for d in scene.draws))
     _check(out, ref, scene.name, depth=any(d.depth_test for d in scene.draws))
 
 
-@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr", "mips", "aniso"])
+@pytest.mark.parametrize("case", ["hello", "random_small", "sphere_small", "textured", "pbr", "mips", "aniso", "alpha_mask"])
 def test_small_cases_srgb8(mirhi, oracle, device, scenes, case):
     scene = scenes.SMALL_CASES[case]()
     out, ref = _render_both(mirhi, oracle, device, scene, fmt=mirhi.Format.B8G8R8A8_SRGB)

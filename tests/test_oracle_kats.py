@@ -275,15 +275,26 @@ def test_k7_pbr_pixel_closed_form(oracle, scenes, metallic, roughness):
 
 def test_k7_pbr_alpha_cutoff(oracle, scenes):
     """model_pbr.hlsl:174-178: constant alpha below the cutoff removes the draw; a textured base colour whose texels
-    could straddle the cutoff is refused (per-fragment discard is outside the restated path)."""
+    straddle the cutoff loses exactly the fragments whose filtered alpha is below it (colour, depth and id untouched)."""
     sc = scenes.SMALL_CASES["pbr"]()
     r = oracle.render(sc)
     nt = sc.draws[0].num_triangles
     drawn = set(np.unique(r["prim"][r["prim"] != 0xFFFFFFFF] // nt).tolist())
     assert drawn == {0, 1, 2, 4}
-    sc.draws[4].material = scenes.pbr_material_ubo((0.3, 0.4, 0.9, 0.6), alpha_cutoff=0.25, has_base_color=True)
-    with pytest.raises(RuntimeError, match="oracle_render failed: 2"):
-        oracle.render(sc)
+    # a textured base colour whose texel alpha straddles the cutoff is discarded fragment by fragment: the left half of this quad's
+    # texture has alpha 0 (discarded: the clear colour and NO_PRIM stay), the right half alpha 255 (kept)
+    tex = np.full((8, 8, 4), 255, dtype=np.uint8)
+    tex[:, :4, 3] = 0
+    quad = _textured_quad_scene(scenes, scenes.Texture(tex), 64, 64, 1.0)
+    d = quad.draws[0]
+    d.program = scenes.PROGRAM_MODEL_PBR
+    d.material = scenes.pbr_material_ubo((1.0, 1.0, 1.0, 1.0), alpha_cutoff=0.5, has_base_color=True)
+    r = oracle.render(quad)
+    kept = r["prim"] != 0xFFFFFFFF
+    # bilinear alpha crosses 0.5 exactly between texel columns 3 and 4 = at u = 0.5: pixel centres left of it are discarded
+    assert not kept[:, :32].any() and kept[:, 32:].all()
+    assert np.allclose(r["rgba"][:, :32], np.array(quad.clear_color, dtype=np.float32))
+    assert (r["depth"][:, :32] == quad.clear_depth).all()
 
 
 # ------------------------------------------------------------------------------------------------
