@@ -68,6 +68,10 @@ __device__ __forceinline__ void ordered_record(const RecRegs& r, uint32_t box, i
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
     const bool boxed = (m & 0x80000000u) != 0u;
     DrawRef D = const_draws(P.draws)[P.num_draws > 1 ? find_draw(P, prim) : 0u];
+    // every block of the record shades the same triangle: its vertex indices are fetched once (a uniform address), so a block's
+    // fragment program starts at the vertex fetch, one dependent memory round trip later than the record, not two
+    uint32_t vin[3];
+    fetch_triangle_indices(D, prim - D.prim_base, vin);
 #pragma unroll 1
     for (int b = 0; b < 4; b++) {
         const int bx = b & 1, by = b >> 1;
@@ -88,11 +92,10 @@ __device__ __forceinline__ void ordered_record(const RecRegs& r, uint32_t box, i
         const uint32_t px = px0 + (uint32_t)bx * BLOCK, py = py0 + (uint32_t)by * BLOCK;
         f4 src = {0.0f, 0.0f, 0.0f, 0.0f};
         if (pass) {
-            const uint32_t tri = prim - D.prim_base;
             const float pxc = (float)px + 0.5f, pyc = (float)py + 0.5f;
-            if (PROGS == 1) src = shade_triangle_program(D, tri, pxc, pyc);
-            else if (PROGS == 2) src = shade_model_program<false>(D, tri, pxc, pyc);
-            else src = (D.program == 0) ? shade_triangle_program(D, tri, pxc, pyc) : shade_model_program<PROGS == 4>(D, tri, pxc, pyc);
+            if (PROGS == 1) src = shade_triangle_program(D, vin, pxc, pyc);
+            else if (PROGS == 2) src = shade_model_program<false>(D, vin, pxc, pyc);
+            else src = (D.program == 0) ? shade_triangle_program(D, vin, pxc, pyc) : shade_model_program<PROGS == 4>(D, vin, pxc, pyc);
         }
         // `if (baseColor.a < alphaCutoff) discard;` (pixel/model_pbr.hlsl:176-179; the program's alpha output is baseColor.a): a discarded
         // fragment writes neither colour nor depth nor its primitive id
@@ -164,20 +167,33 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
     if (!may_skip) load_state();
     const uint4* slots = reinterpret_cast<const uint4*>(P.ordered_recs);
     const uint4* pieces = reinterpret_cast<const uint4*>(P.big_recs);
+    // the box word of the NEXT chunk's slot is requested while this chunk is handled: the scan over the segment's slots then
+    // runs at the rate of its barriers, not of a memory round trip per chunk
+    // (lanes beyond the segment's end read its last slot -- a valid address -- and ignore it)
+    const uint32_t last = P.ordered_count ? P.ordered_count - 1u : 0u;
+    uint4 w2_next = make_uint4(0u, 0u, 0u, 0u);
+    if (P.ordered_count) w2_next = slots[(size_t)(tid < last ? tid : last) * 3u + 2u];
     for (uint32_t base = 0; base < P.ordered_count; base += ORDERED_THREADS) {
         // ---- classify this thread's slot ----
         const uint32_t i = base + tid;
-        uint4 w2 = make_uint4(0u, 0u, 1u, 0u);
-        if (i < P.ordered_count) w2 = slots[(size_t)i * 3u + 2u];
-        const bool marker = w2.w == ORDERED_MARKER;
+        const uint4 w2 = w2_next;
+        {
+            const uint32_t nx = i + (uint32_t)ORDERED_THREADS;
+            w2_next = slots[(size_t)(nx < last ? nx : last) * 3u + 2u];
+        }
+        const bool live = i < P.ordered_count;
+        const bool marker = live && w2.w == ORDERED_MARKER;
         const int32_t minx = (int32_t)(w2.z & 0x7FFFu), maxx = (int32_t)((w2.z >> 16) & 0x7FFFu);
         const int32_t miny = (int32_t)(w2.w & 0xFFFFu), maxy = (int32_t)(w2.w >> 16);
-        const bool overlap = !marker && !(maxx < minx) && !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
+        const bool overlap = live && !marker && !(maxx < minx) && !(maxx < tpx0 || minx > tpx0 + TILE - 1 || maxy < tpy0 || miny > tpy0 + TILE - 1);
         {
             const uint64_t mb = __ballot(marker);
             if (lane == 0) { lds_marker[q * 2u] = (uint32_t)mb; lds_marker[q * 2u + 1u] = (uint32_t)(mb >> 32); }
         }
-        __syncthreads();
+        // Most chunks of a segment hold nothing for this tile (256 scattered 50-pixel triangles reach a given tile one time in five):
+        // such a chunk costs its one 16-byte load per lane and this barrier, not the three staging barriers below.  (Nobody reads
+        // lds_marker in that case, so the next chunk may overwrite it right away.)
+        if (!__syncthreads_or((int)(overlap || marker))) continue;
         // ---- sub-ranges [lo, hi) of the chunk between markers ----
         uint32_t lo = 0;
         while (lo < (uint32_t)ORDERED_THREADS) {

@@ -183,12 +183,13 @@ __device__ __forceinline__ void barycentrics(DrawRef D, const f4 c[3], float pxc
 // operation order: for a sliver triangle the three lambdas nearly cancel, and a contracted FMA or the 1-ulp rcp then shows
 // up as 1e-3 in the interpolated colour (found by the 60000-scene soak of tools/soak_fuzz.py; one pixel in ~3000 scenes).
 // With w = 1 the homogeneous form is ax_k = (x_k * W/2 + cx) - px.  Flat-coloured triangles never get here (flat_color).
-__device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
+// vin: the triangle's three vertex indices (fetch_triangle_indices), which a caller that shades the same triangle several times
+// fetches once
+__device__ __forceinline__ f4 shade_triangle_program(DrawRef D, const uint32_t vin[3], float pxc, float pyc) {
     float ax[3], ay[3]; f3 col[3];
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint32_t vidx = fetch_index(D, 3u * tri + k);
-        const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+        const uint8_t* v = D.vb + (size_t)vin[k] * D.stride;
         ax[k] = (ldf(v, 0) * D.hw + D.cx) - pxc;                             // vertex/triangle.hlsl:19-20
         ay[k] = (ldf(v, 4) * D.hh + D.cy) - pyc;
         col[k] = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
@@ -200,6 +201,15 @@ __device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, fl
     const float b[3] = {l0 * inv, l1 * inv, l2 * inv};
     const f3 o = interp3(b, col[0], col[1], col[2]);                         // pixel/triangle.hlsl:10-13
     return {o.x, o.y, o.z, 1.0f};
+}
+__device__ __forceinline__ void fetch_triangle_indices(DrawRef D, uint32_t tri, uint32_t vin[3]) {
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) vin[k] = fetch_index(D, 3u * tri + k);
+}
+__device__ __forceinline__ f4 shade_triangle_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
+    uint32_t vin[3];
+    fetch_triangle_indices(D, tri, vin);
+    return shade_triangle_program(D, vin, pxc, pyc);
 }
 
 // a8: Cook-Torrance GGX, shaders/hlsl/pbr.hlsli (shadow pass not on the path: shadow = 1)
@@ -326,13 +336,12 @@ __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const uint3
 
 // FULL: the variant that also carries the Cook-Torrance program and mip-mapped (trilinear) sampling
 template <bool FULL>
-__device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
-    f4 c[3]; uint32_t vi[3];
+__device__ __forceinline__ f4 shade_model_program(DrawRef D, const uint32_t vi[3], float pxc, float pyc) {
+    f4 c[3];
     const bool full = D.program >= 2;
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel: the clip position first
-        vi[k] = fetch_index(D, 3u * tri + k);
         const uint4 w0 = (reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words)[0];
         c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
     }
@@ -448,6 +457,13 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float
     }
     const f3 col = add3(ambient, lighting);
     return {col.x, col.y, col.z, albedoSample.w * baseColor.w};
+}
+
+template <bool FULL>
+__device__ __forceinline__ f4 shade_model_program(DrawRef D, uint32_t tri, float pxc, float pyc) {
+    uint32_t vin[3];
+    fetch_triangle_indices(D, tri, vin);
+    return shade_model_program<FULL>(D, vin, pxc, pyc);
 }
 
 #pragma clang fp contract(fast)
