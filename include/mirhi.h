@@ -183,9 +183,10 @@ typedef struct {
     uint32_t color_write_mask;          /* bit 0 R, 1 G, 2 B, 3 A */
     /* default 0.  The MODEL_PBR fragment program ends fragments whose base-colour alpha is below the material's alphaCutoff
      * (`discard`, pixel/model_pbr.hlsl:176-179).  With a base colour texture that is a decision per fragment, taken before the depth
-     * write: pipelines for alpha-masked materials (glTF alphaMode MASK) set this, and their draws are resolved fragment by fragment
-     * in primitive order like blended ones (DESIGN.md "Ordered segments").  Without it such a draw is refused loudly at the fence
-     * ("alpha cutoff"); draws whose alpha cannot cross the cutoff (no texture, or cutoff <= 0) never need it. */
+     * write: pipelines for alpha-masked materials (glTF alphaMode MASK) set this.  Their draws form a rendering-scope segment of their
+     * own whose raster kernel tests alpha per covered pixel in front of the depth key (blended or predicate-depth-state ones are resolved
+     * fragment by fragment in primitive order instead, DESIGN.md "Ordered segments").  Without it such a draw is refused loudly at the
+     * fence ("alpha cutoff"); draws whose alpha cannot cross the cutoff (no texture, or cutoff <= 0) never need it. */
     uint32_t fragment_discard_enable;
 } mirhi_pipeline_desc;
 void         mirhi_pipeline_desc_default(mirhi_pipeline_desc* desc);                      /* GraphicsPipelineBuilder::new :645-698 */

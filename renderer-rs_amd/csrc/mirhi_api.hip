@@ -1055,8 +1055,22 @@ static mirhi_result grow(T** ptr, size_t* have, size_t want_bytes) {
 // A segment is resolved fragment by fragment in primitive order (ordered_kernel) when its colour is blended, when its
 // depth state makes the stored depth depend on the order of all fragments (NotEqual with depth write), or when its fragment
 // program may discard single fragments (mirhi_pipeline_desc::fragment_discard_enable: visibility then needs the program's result).
+static void depth_key_setup(PassParams& P, const RecordedPass& pass);
+// fragment_discard_enable without blending under a depth state the depth key resolves by minimum (not a predicate state): visibility stays
+// order-independent -- a kept fragment competes by its key -- so the segment keeps bins and the raster kernel, and alpha is tested per
+// covered pixel in front of the key minimum (PassParams::alpha_scope, raster_small_masked).  MIRHI_MASKED_ORDERED=1 (A/B runs): the
+// ordered resolve instead.
+static bool pass_is_masked_plain(const RecordedPass& pass) {
+    if (!pass.key_set || !pass.frag_discard || pass.blend[0] != 0) return false;
+    if (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL) return false;
+    if (getenv("MIRHI_MASKED_ORDERED") && atoi(getenv("MIRHI_MASKED_ORDERED")) != 0) return false;
+    PassParams key{};
+    depth_key_setup(key, pass);
+    return key.pred == 0u;
+}
 static bool pass_is_ordered(const RecordedPass& pass) {
-    return pass.key_set && (pass.blend[0] != 0 || pass.frag_discard != 0 || (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL));
+    return pass.key_set && (pass.blend[0] != 0 || (pass.frag_discard != 0 && !pass_is_masked_plain(pass)) ||
+                            (pass.depth_test && pass.depth_write && pass.depth_compare == MIRHI_COMPARE_NOT_EQUAL));
 }
 
 static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
@@ -1117,6 +1131,7 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles) {
     const bool dense = tiles && avg >= density;
     m.tp_max_area = getenv("MIRHI_TP_MAX_AREA") ? (uint32_t)atoi(getenv("MIRHI_TP_MAX_AREA")) : (dense ? 64u : 0u);
     if (key.pred) m.tp_max_area = 0;      // predicate scopes resolve pixel-parallel only (the LDS key array holds ordered keys)
+    else if (pass_is_masked_plain(pass) && m.tp_max_area == 0u) m.tp_max_area = 1u;    // alpha-masked scope: its records need the triangle-parallel path (LDS key array)
     const bool mesh_only = !m.tri_prog && !pass.draws.empty();
     m.teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : (avg < 16 ? 2u : 1u);
     if (!(m.tp_max_area && mesh_only && !pass_is_ordered(pass)) || m.teams != 2u) m.teams = 1u;
@@ -1345,6 +1360,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         {
             const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0));
             P.tp_max_area = mode.tp_max_area;
+            P.alpha_scope = pass_is_masked_plain(pass) ? 1u : 0u;
             P.raster_teams = mode.teams;
             P.sub_cap = g.sub_cap;
             P.count_stride = g.xcd_bins ? (uint32_t)max_tiles : 0u;

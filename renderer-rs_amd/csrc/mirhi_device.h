@@ -160,6 +160,8 @@ struct PassParams {
     TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;
     uint32_t ord_depth_test, ord_depth_write, ord_depth_op;
     uint32_t blend[8];                // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
+    uint32_t alpha_scope;             // 1: a plain (bins + depth key) scope whose pipelines set fragment_discard_enable: records of draws whose texel
+                                      // alpha straddles the material's cutoff are resolved triangle-parallel with the alpha test per pixel (raster_small_masked)
     uint32_t* status;                 // pinned host memory: [0] status bits (atomicOr), [1] big-list length, [2] dynamic pages of the last scope
     unsigned long long* frag_stats;   // device counters of the statistics pass (never touched by geometry / raster kernels): [0] pixels that
                                       // ran a fragment program (winners of the depth resolve), [1] fragments covered before the depth test

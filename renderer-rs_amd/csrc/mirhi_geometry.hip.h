@@ -503,14 +503,15 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     if (D.program == 3) {
         // pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` decided per draw where one decision covers it: alpha is
         // baseColorFactor.a, or a texel alpha in [0,1] times it.  A draw whose texels could fall on both sides of the cutoff needs the
-        // discard per fragment, before the depth write: an ordered segment does that (fragment_discard_enable routes the draw there,
-        // ordered_record); anywhere else it is reported, not rendered.
+        // discard per fragment, before the depth write: fragment_discard_enable routes the draw to a scope that does that (alpha_scope:
+        // raster_small_masked tests alpha in front of the depth key; an ordered segment: ordered_record); anywhere else it is reported,
+        // not rendered.
         const CBytePtr M = cb(D.material);
         const float fa = ldcf(M, 12), cutoff = ldcf(M, 44);
         float lo = fa, hi = fa;
         if (ldcu(M, 48) != 0u) { lo = fa < 0.0f ? fa : 0.0f; hi = fa > 0.0f ? fa : 0.0f; }
         if (hi < cutoff) dropped = true;
-        else if (!(lo >= cutoff) && !P.ordered_recs) {
+        else if (!(lo >= cutoff) && !P.ordered_recs && !P.alpha_scope) {
             dropped = true;
             if (threadIdx.x == 0) __hip_atomic_fetch_or(P.status, STATUS_ALPHA_TEST_TEXTURED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -66,8 +66,14 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
 }
 
 template <int KEYED, int TP, int TEAMS = 1>
-static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream, LaunchTiming t) {
+static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t programs, dim3 grid, hipStream_t stream, LaunchTiming t, bool masked = false) {
     const dim3 block(RASTER_THREADS * TEAMS);
+    if constexpr (TP != 0) {    // alpha-masked scope (host: PassParams::alpha_scope, always with the triangle-parallel path and a PBR draw)
+        if (masked) {
+            MIRHI_LAUNCH((raster_kernel<4, KEYED, TP, TEAMS, true>), grid, block, stream, t, P, H);
+            return;
+        }
+    }
     if (TEAMS > 1) {            // only the pure mesh variants exist with two teams (launch_raster checks)
         if (programs == 2) MIRHI_LAUNCH((raster_kernel<2, KEYED, TP, TEAMS>), grid, block, stream, t, P, H);
         else MIRHI_LAUNCH((raster_kernel<4, KEYED, TP, TEAMS>), grid, block, stream, t, P, H);
@@ -97,9 +103,9 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
     if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream, t);          // (the host keeps tp_max_area = 0 for predicate scopes)
     else if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) {
-        if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream, t);
+        if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u);
     }
-    else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream, t); }
+    else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); }
     else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream, t); }
     return hipGetLastError();
 }
@@ -173,7 +179,7 @@ hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* co
     (void)plain;
     return hipGetLastError();
 }
-bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs; }
+bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs && !P.alpha_scope; }
 
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;

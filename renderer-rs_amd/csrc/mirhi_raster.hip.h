@@ -272,17 +272,82 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
     }
 }
 
+// bit 30 of a tile record's mask word: a record of an alpha-masked draw that is resolved pixel-parallel (see raster_record_masked)
+#define MIRHI_REC_MASKED 0x40000000u
+
+// One record of an alpha-masked Cook-Torrance draw against the four blocks of this wave, pixel-parallel (records whose pixel box is
+// too large for the triangle-parallel walk of raster_small_masked): coverage as raster_record, then the fragment program's alpha
+// (pbr_base_alpha: the shading path's bits) on the covered lanes, and only fragments it keeps compete by their depth key.  The
+// triangle's clip positions and texture coordinates are fetched once per record (a uniform address).
+template <int KEYED>
+__device__ __forceinline__ void raster_record_masked(const RecRegs& r, int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
+                                                     PixelState& st, uint32_t qbit0, uint32_t tx, uint32_t ty) {
+    const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
+    const int32_t B0 = (int32_t)r.w1.z, B1 = (int32_t)r.w1.w, B2 = (int32_t)r.w2.x;
+    const float z0 = __uint_as_float(r.w2.w), zx = __uint_as_float(r.w3.x), zy = __uint_as_float(r.w3.y);
+    const uint32_t idk = __builtin_amdgcn_readfirstlane(r.w3.z);
+    const uint32_t m = __builtin_amdgcn_readfirstlane(r.w3.w);
+    const uint32_t prim = P.idflip ? (MAX_PRIM_ID - idk) : idk;
+    DrawRef D = const_draws(P.draws)[P.num_draws > 1 ? find_draw(P, prim) : 0u];
+    uint32_t vin[3];
+    fetch_triangle_indices(D, prim - D.prim_base, vin);
+    f4 c[3]; float uvk[3][2];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vin[k] * D.vs_words;
+        const uint4 w0 = sv[0], w2 = sv[2];
+        c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+        uvk[k][0] = __uint_as_float(w2.z); uvk[k][1] = __uint_as_float(w2.w);
+    }
+    const float cutoff = ldcf(cb(D.material), 44);
+    const int32_t s0 = mad24(B0, iy0, mad24(A0, ix0, (int32_t)r.w0.x));
+    const int32_t s1 = mad24(B1, iy0, mad24(A1, ix0, (int32_t)r.w0.y));
+    const int32_t s2 = mad24(B2, iy0, mad24(A2, ix0, (int32_t)r.w0.z));
+    const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
+    const float pxc0 = (float)(tx * TILE + (uint32_t)ix0) + 0.5f, pyc0 = (float)(ty * TILE + (uint32_t)iy0) + 0.5f;
+#pragma unroll 1
+    for (int b = 0; b < 4; b++) {
+        const int bx = b & 1, by = b >> 1;
+        if (!(m & (qbit0 << (by * 4 + bx)))) continue;
+        const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK, S1 = s1 + (A1 * bx + B1 * by) * BLOCK, S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
+        bool inside = (S0 | S1 | S2) >= 0;
+        if (__ballot(inside) == 0ull) continue;
+        if (inside) inside = !(pbr_base_alpha(D, c, uvk, pxc0 + (float)(bx * BLOCK), pyc0 + (float)(by * BLOCK)) < cutoff);
+        const float dx = dx0 + (float)(bx * BLOCK), dy = dy0 + (float)(by * BLOCK);
+        const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+        uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+        if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
+        const uint32_t zo = b == 0 ? st.zk[0] : (b == 1 ? st.zk[1] : (b == 2 ? st.zk[2] : st.zk[3]));
+        const uint32_t io = b == 0 ? st.idk[0] : (b == 1 ? st.idk[1] : (b == 2 ? st.idk[2] : st.idk[3]));
+        const bool upd = inside && (((uint64_t)zk << 32) | idk) < (((uint64_t)zo << 32) | io);
+        if (b == 0) { st.zk[0] = upd ? zk : zo; st.idk[0] = upd ? idk : io; }
+        else if (b == 1) { st.zk[1] = upd ? zk : zo; st.idk[1] = upd ? idk : io; }
+        else if (b == 2) { st.zk[2] = upd ? zk : zo; st.idk[2] = upd ? idk : io; }
+        else { st.zk[3] = upd ? zk : zo; st.idk[3] = upd ? idk : io; }
+    }
+}
+
 // all records of an LDS chunk: per 64 records one ballot builds the bitmap of records that touch this
 // wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
-template <int KEYED, int TP>
+template <int KEYED, int TP, bool MASKED = false>
 __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
                                              int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
-                                             PixelState& st, uint32_t qbit0, uint32_t lane) {
+                                             PixelState& st, uint32_t qbit0, uint32_t lane, uint32_t tx = 0u, uint32_t ty = 0u) {
     for (uint32_t g = 0; g < n; g += 64u) {
         const uint32_t j = g + lane;
         const uint32_t mymask = j < n ? lds_rec[j * 4u + 3u].w : 0u;
         const bool rel = (mymask & qmask) != 0u, boxed = !TP && (mymask & 0x80000000u) != 0u;
-        uint64_t bits = __ballot(rel && !boxed);
+        const bool mrec = MASKED && (mymask & MIRHI_REC_MASKED) != 0u;
+        if (MASKED) {        // (alpha-masked scopes only: no such record exists elsewhere)
+            uint64_t mbits = __ballot(rel && mrec);
+            while (mbits) {
+                const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)mbits) - 1);
+                mbits &= mbits - 1;
+                const RecRegs cur = load_rec(lds_rec, cur_j);
+                raster_record_masked<KEYED>(cur, ix0, iy0, fix0, fiy0, P, st, qbit0, tx, ty);
+            }
+        }
+        uint64_t bits = __ballot(rel && !boxed && !mrec);
         while (bits) {
             const uint32_t bit = (uint32_t)(__ffsll((long long)bits) - 1);
             // clear the bit with one scalar instruction (the compiler's `bits &= bits - 1` is add, addc, and: the scalar unit issues
@@ -349,6 +414,58 @@ __device__ __forceinline__ void raster_small(const uint4 rec[4], uint32_t box, u
     }
 }
 
+// The same walk for a record of an alpha-masked Cook-Torrance draw (PassParams::alpha_scope): the fragment program ends a fragment
+// whose base-colour alpha is below the material's cutoff BEFORE the depth write (`discard`, pixel/model_pbr.hlsl:176-179), so the
+// alpha is evaluated here, per covered pixel, in front of the key minimum -- with the shading path's own barycentrics, (u, v),
+// footprint and lookup (pbr_base_alpha), i.e. the bits the oracle's fragment loop compares.  Visibility stays order-independent:
+// a kept fragment competes by its depth key like any other.  D is wave-uniform (the caller's waterfall over the wave's draws).
+template <int KEYED>
+__device__ __forceinline__ void raster_small_masked(DrawRef D, uint32_t prim, const uint4 rec[4], uint32_t box, unsigned long long* lds_key,
+                                                    ParamsRef P, uint32_t tx, uint32_t ty) {
+    uint32_t vin[3];
+    fetch_triangle_indices(D, prim - D.prim_base, vin);
+    f4 c[3]; float uvk[3][2];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vin[k] * D.vs_words;
+        const uint4 w0 = sv[0], w2 = sv[2];
+        c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
+        uvk[k][0] = __uint_as_float(w2.z); uvk[k][1] = __uint_as_float(w2.w);
+    }
+    const float cutoff = ldcf(cb(D.material), 44);
+    const int32_t A0 = (int32_t)rec[0].w, A1 = (int32_t)rec[1].x, A2 = (int32_t)rec[1].y;
+    const int32_t B0 = (int32_t)rec[1].z, B1 = (int32_t)rec[1].w, B2 = (int32_t)rec[2].x;
+    const float dxt = __uint_as_float(rec[2].y), dyt = __uint_as_float(rec[2].z), z0 = __uint_as_float(rec[2].w);
+    const float zx = __uint_as_float(rec[3].x), zy = __uint_as_float(rec[3].y);
+    const uint32_t idk = rec[3].z;
+    const int32_t bx0 = (int32_t)(box & 0xFF), bx1 = (int32_t)((box >> 8) & 0xFF);
+    const int32_t by0 = (int32_t)((box >> 16) & 0xFF), by1 = (int32_t)(box >> 24);
+    int32_t r0 = mad24(B0, by0, mad24(A0, bx0, (int32_t)rec[0].x));
+    int32_t r1 = mad24(B1, by0, mad24(A1, bx0, (int32_t)rec[0].y));
+    int32_t r2 = mad24(B2, by0, mad24(A2, bx0, (int32_t)rec[0].z));
+    const float px_base = (float)(tx * TILE) + 0.5f, py_base = (float)(ty * TILE) + 0.5f;      // (exact: integers below 2^14 plus a half)
+#pragma unroll 1
+    for (int32_t iy = by0; iy <= by1; iy++) {
+        int32_t s0 = r0, s1 = r1, s2 = r2;
+        const float dy = (float)iy + dyt;
+#pragma unroll 1
+        for (int32_t ix = bx0; ix <= bx1; ix++) {
+            if ((s0 | s1 | s2) >= 0) {
+                const float alpha = pbr_base_alpha(D, c, uvk, px_base + (float)ix, py_base + (float)iy);
+                if (!(alpha < cutoff)) {
+                    const float dx = (float)ix + dxt;
+                    const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
+                    uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
+                    if (KEYED == 1) zk = (zk ^ P.zflip) & P.zmask;
+                    atomicMin(&lds_key[iy * TILE + ix], ((unsigned long long)zk << 32) | idk);
+                }
+            }
+            s0 += A0; s1 += A1; s2 += A2;
+        }
+        r0 += B0; r1 += B1; r2 += B2;
+    }
+}
+
 __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, bool valid, uint32_t& zk,
                                          uint32_t& idk, uint32_t& zorig) {
     zk = P.init_zk; idk = P.init_idk; zorig = P.clear_depth_bits;
@@ -373,7 +490,7 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // sub-bins before k, so that flat index i lives in sub-bin #{k >= 1 : i >= seg[k]} at offset i - seg[that].  nullptr: a plain list.
 // bins: `list` is the bin pool and flat index i of the tile's bin lives in pool page pages[...] (LDS copy of the tile's page-table
 // row; the first page of a single-list bin is page `tile` itself); otherwise `list` is a plain TriRec array (the big list).
-template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS>
+template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS, bool MASKED = false>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint32_t tile, uint32_t fixed_recs, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
@@ -433,6 +550,34 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             small = bw * bh <= P.tp_max_area;
             boxed = (rec[3].w & 0x80000000u) != 0u;
         }
+        // Alpha-masked scope (MASKED variants: PROGS = 4 with the triangle-parallel path): records of draws whose fragments are
+        // alpha-tested one by one leave here, whatever their size.  Waterfall over the draws present in the wave, so the draw
+        // descriptor (viewport, texture, material) stays wave-uniform.
+        if (MASKED && P.alpha_scope) {
+            uint32_t prim = 0u, mydraw = 0xFFFFFFFFu;
+            if (hit) {
+                prim = P.idflip ? (MAX_PRIM_ID - rec[3].z) : rec[3].z;
+                mydraw = P.num_draws > 1 ? find_draw(P, prim) : 0u;
+            }
+            uint64_t todo = __ballot(hit);
+            while (todo) {
+                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mydraw, __ffsll((long long)todo) - 1);
+                const bool mine = hit && mydraw == d;
+                DrawRef D = const_draws(P.draws)[__builtin_amdgcn_readfirstlane((int)d)];
+                if (draw_needs_alpha_test(D)) {                      // (wave-uniform)
+                    // small pixel boxes (and scissor-cut records, which need the box): the lane that built the record walks it;
+                    // larger ones are staged with the masked bit and resolved pixel-parallel by raster_record_masked
+                    const uint32_t mbw = ((box >> 8) & 0xFF) - (box & 0xFF) + 1u, mbh = (box >> 24) - ((box >> 16) & 0xFF) + 1u;
+                    const bool walk = mbw * mbh <= 64u || (rec[3].w & 0x80000000u) != 0u;
+                    if (mine && walk) {
+                        raster_small_masked<KEYED>(D, prim, rec, box, lds_key, P, txl, tyl);
+                        hit = false;
+                    }
+                    if (mine && !walk) { rec[3].w |= MIRHI_REC_MASKED; small = false; }
+                }
+                todo &= ~__ballot(mine);
+            }
+        }
         // Triangle-parallel only pays when the wave holds enough small records to keep its lanes busy (meshes of small
         // triangles); a few stragglers in a sparse tile would serialise their pixel loops while 3 waves wait.
         if (TP) {
@@ -456,7 +601,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         const uint32_t n = *cnt;
         flip ^= 1u;
         if (base0 == 0) { STAMP(5); STAGE_END(2u); }
-        if (n) raster_chunk<KEYED, TP>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane);
+        if (n) raster_chunk<KEYED, TP, MASKED>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane, txl, tyl);
     }
 }
 
@@ -471,7 +616,10 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // through LDS at the end, then each team shades half of the tile's pixels.  No traffic through memory and no extra
 // workgroups, unlike sharing a tile between workgroups ("measured and not adopted").  On frames that already
 // fill the chip the wider workgroups only cost occupancy (C4 raster 109 -> 156 us, C5 202 -> 272 us), hence the host's choice.
-template <int PROGS, int KEYED, int TP, int TEAMS = 1>
+// MASKEDV: the variant of an alpha-masked scope (PassParams::alpha_scope; PROGS = 4 with TP): carries raster_small_masked and
+// raster_record_masked -- its own variant so that the scopes without masked materials keep their registers (the two paths cost
+// the PROGS = 4 kernels 48-78 scalar registers spilled to vector lanes and 2 % of the dancer asset's frame).
+template <int PROGS, int KEYED, int TP, int TEAMS = 1, bool MASKEDV = false>
 #ifndef MIRHI_PROGS2_WAVES
 #define MIRHI_PROGS2_WAVES 5
 #endif
@@ -613,7 +761,8 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // the tile's bin (32-byte records in pool pages), then the list every tile tests (48-byte records: large / clipped / scissor-cut /
     // spilled triangles).  Two instantiations of raster_list: one body fed from either source has to hold both record forms in
     // registers on the way to the tile record, which the TRIANGLE-only variants (64 VGPRs) pay with ~20 spills.
-    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, H.fixed_recs, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    constexpr bool MASKED = MASKEDV && PROGS == 4 && TP != 0;
+    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true, MASKED>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, H.fixed_recs, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
     STAMP(2);
     if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
@@ -623,7 +772,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
     if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
     // parameters of this phase are (re)read here, see launder_params
-    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, 0u, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false, MASKED>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, 0u, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
 
     STAMP(3);
@@ -776,9 +925,9 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
 
 #define MIRHI_RASTER_BOUNDS __launch_bounds__(RASTER_THREADS * TEAMS, (PROGS == 1 ? (TP ? 7 : 8) : (PROGS == 2 ? MIRHI_PROGS2_WAVES : 4)))
 // one rendering scope: grid (tiles_x, tile rows of the band)
-template <int PROGS, int KEYED, int TP, int TEAMS = 1>
+template <int PROGS, int KEYED, int TP, int TEAMS = 1, bool MASKEDV = false>
 __global__ MIRHI_RASTER_BOUNDS void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
-    raster_body<PROGS, KEYED, TP, TEAMS>(params, H);
+    raster_body<PROGS, KEYED, TP, TEAMS, MASKEDV>(params, H);
 }
 // up to MAX_BATCH independent rendering scopes of equal shape (the frames of one mirhi_queue_submit): grid (tiles_x, tile rows, scopes).
 // One launch instead of one per frame: the ramp-up and drain of a kernel (5 us of the 11 us an isolated 10k-triangle raster kernel

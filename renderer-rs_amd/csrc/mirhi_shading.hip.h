@@ -250,6 +250,37 @@ __device__ __forceinline__ f3 pbr_direct(f3 N, f3 V, f3 L, f3 radiance, const Pb
             ((div_rn_nb(kD.z * m.albedo.z, PBR_PI) + specular.z) * radiance.z) * NdotL};
 }
 
+// alpha the Cook-Torrance program compares with alphaCutoff (pixel/model_pbr.hlsl:166-179) at one pixel of a draw with a base colour
+// texture: the same barycentrics, (u, v), footprint and lookup as shade_model_program / shade_pbr, so the same bits
+__device__ __forceinline__ float pbr_base_alpha(DrawRef D, const f4 c[3], const float uvk[3][2], float pxc, float pyc) {
+    float b[3];
+    barycentrics<false>(D, c, pxc, pyc, b);
+    float u = 0.0f, v = 0.0f;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) { acc1(u, b[k], uvk[k][0], k); acc1(v, b[k], uvk[k][1], k); }
+    UvGrad grad = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (D.tex_any_mips) {
+        float bx[3], by[3];
+        barycentrics<false>(D, c, pxc + 1.0f, pyc, bx);
+        barycentrics<false>(D, c, pxc, pyc + 1.0f, by);
+        grad.dudx = ((bx[0] * uvk[0][0] + bx[1] * uvk[1][0]) + bx[2] * uvk[2][0]) - u;
+        grad.dvdx = ((bx[0] * uvk[0][1] + bx[1] * uvk[1][1]) + bx[2] * uvk[2][1]) - v;
+        grad.dudy = ((by[0] * uvk[0][0] + by[1] * uvk[1][0]) + by[2] * uvk[2][0]) - u;
+        grad.dvdy = ((by[0] * uvk[0][1] + by[1] * uvk[1][1]) + by[2] * uvk[2][1]) - v;
+    }
+    return sample_texture<true>(D, 0, u, v, grad).w * ldcf(cb(D.material), 12);
+}
+// true if the draw's fragments have to be alpha-tested one by one: MODEL_PBR with a base colour texture whose texel alpha (in [0, 1]
+// times baseColorFactor.a) can fall on both sides of alphaCutoff -- the decision geometry_body takes per draw otherwise
+__device__ __forceinline__ bool draw_needs_alpha_test(DrawRef D) {
+    if (D.program != 3u) return false;
+    const CBytePtr M = cb(D.material);
+    const float fa = ldcf(M, 12), cutoff = ldcf(M, 44);
+    if (ldcu(M, 48) == 0u) return false;
+    const float lo = fa < 0.0f ? fa : 0.0f, hi = fa > 0.0f ? fa : 0.0f;
+    return !(hi < cutoff) && !(lo >= cutoff);
+}
+
 // pixel/model_pbr.hlsl:159-320 after the shared varying interpolation
 __device__ __forceinline__ f4 shade_pbr(DrawRef D, const float b[3], const uint32_t vi[3], float u, float v, f3 worldPos, f3 V, f3 N, const UvGrad& grad) {
     const CBytePtr M = cb(D.material);                                                  // MaterialData :36-59 (80 B)

@@ -511,3 +511,53 @@ def test_anisotropic_filter_isotropic_footprint_is_trilinear(mirhi, device, scen
         frames.append(res.read()["color"].copy())
         res.destroy()
     assert np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.parametrize("teams", ["1", "2"])
+@pytest.mark.parametrize("state", ["less", "greater", "always_nowrite", "equal_nowrite", "ordered_env"])
+def test_alpha_masked_materials_every_resolve_path(mirhi, oracle, device, scenes, monkeypatch, teams, state):
+    """Alpha-masked Cook-Torrance draws (`discard`, model_pbr.hlsl:176-179) through each way the library resolves them: the masked
+    raster variants (plain key: LESS; generic key: GREATER; no depth write: later primitive wins), one and two teams per tile,
+    small boxes walked by the lane that built them and large ones pixel-parallel (the case has both) -- and the ordered resolve
+    where the key cannot decide (a predicate depth state) or where MIRHI_MASKED_ORDERED asks for it."""
+    monkeypatch.setenv("MIRHI_RASTER_TEAMS", teams)
+    if state == "ordered_env":
+        monkeypatch.setenv("MIRHI_MASKED_ORDERED", "1")
+    scene = scenes.SMALL_CASES["alpha_mask"]()
+    for d in scene.draws:
+        if state == "greater":
+            d.depth_compare = scenes.CMP_GREATER
+        elif state == "always_nowrite":
+            d.depth_compare, d.depth_write = scenes.CMP_ALWAYS, False
+        elif state == "equal_nowrite" and d is not scene.draws[0]:
+            d.depth_compare, d.depth_write = scenes.CMP_LESS_OR_EQUAL, False
+    if state == "greater":
+        scene.clear_depth = 0.0
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=True)
+    _check(out, ref, f"alpha-mask-{state}-teams{teams}", depth=True)
+    assert (ref["prim"] != 0xFFFFFFFF).sum() > 5000
+
+
+def test_alpha_masked_mesh_of_small_triangles(mirhi, oracle, device, scenes):
+    """A finely tessellated masked sheet (every record takes the triangle-parallel walk) over an opaque scene, mip-free cut-out discs."""
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+    leaf = np.zeros((n, n, 4), dtype=np.uint8)
+    leaf[..., 0] = 60; leaf[..., 1] = 150 + (xx % 8) * 8; leaf[..., 2] = 40
+    leaf[..., 3] = np.clip(255 - np.hypot((xx % 16) - 7.5, (yy % 16) - 7.5) * 30, 0, 255).astype(np.uint8)
+    W, H = 320, 200
+    grid = scenes.heightfield_grid(48, 40, W, H).draws[0]
+    verts = np.ascontiguousarray(grid.vertices).view(np.float32).reshape(-1, 12).copy()
+    verts[:, 6:8] *= 6.0
+    view, proj, cam = scenes.default_camera(W, H, eye=(0.0, 0.0, 5.0))
+    masked = scenes.DrawSpec(vertices=verts, stride=48, count=grid.count, indices=grid.indices, program=scenes.PROGRAM_MODEL_PBR,
+                             cull_mode=scenes.CULL_NONE, camera=cam, object=grid.object,
+                             light=scenes.light_ubo(direction=(0.2, -0.6, -0.8), intensity=1.2, color=(1.0, 1.0, 1.0)),
+                             material=scenes.pbr_material_ubo((1.0, 1.0, 1.0, 1.0), 0.0, 0.6, 1.0, alpha_cutoff=0.5, has_base_color=True),
+                             albedo_map=scenes.Texture(leaf), alpha_test=True)
+    opaque = scenes.random_triangles(200, W, H, seed=5, rmin=4, rmax=40).draws[0]
+    scene = scenes.Scene("masked-sheet", W, H, [opaque, masked], clear_color=(0.1, 0.1, 0.15, 1.0))
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=True)
+    _check(out, ref, scene.name, depth=True)
+    kept = (ref["prim"] >= 200) & (ref["prim"] != 0xFFFFFFFF)
+    assert 0.03 < kept.mean() < 0.8         # the discs keep about a fifth of the sheet, holes show what lies behind
