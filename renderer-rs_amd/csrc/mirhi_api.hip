@@ -157,6 +157,15 @@ struct Workspace {
     uint32_t* bin_table = nullptr; size_t bin_table_bytes = 0; // [tiles][BIN_TABLE_ROW] page table, PAGE_EMPTY when idle
     uint32_t pool_scale = 1;                                   // doubled whenever a scope exhausted the pool (applied at the next submit)
     bool grow_pool = false;
+    // Feedback on the two-team mesh mode (raster_mode picks it from the triangle count alone: 'few triangles per tile' is a mesh
+    // that sits in a part of the frame -- or one spread thinly over all of it, where the wider workgroups only cost occupancy): a
+    // scope that ran in that mode and opened more than two list pages per tile of the frame was spread out (64x64-quad grid over a
+    // 1080p frame: 5,340 pages on 2,040 tiles, raster 41.8 us with two teams, 30.4 us with one; the dancer asset: 1,770 pages, 39 us
+    // against 66 us); the plan is rebuilt with one team.
+    bool spread = false, replan = false;
+    uint64_t spread_tris = 0;                                  // triangles of the command buffer when `spread` was measured: forgotten when the
+                                                               // recorded frame is another one (more than twice / less than half as many)
+    uint32_t xcd_tiles_last = 0;                               // tiles of the command buffer's last scope if it uses per-XCD bins, else 0
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [8 * tiles] bin counts, two big-list counters, the pool counter
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
     VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
@@ -745,6 +754,7 @@ static void reset_recording(mirhi_cmd* c) {
     for (auto& u : c->uniforms) u = {nullptr, 0, 0};
     for (auto& tx : c->textures) tx = nullptr;
     c->has_viewport = c->has_scissor = false;
+    c->ws.replan = false; c->ws.xcd_tiles_last = 0;     // (Workspace::spread survives: a frame loop records the same frame again)
 }
 static mirhi_result begin_common(mirhi_cmd* cmd, bool one_time) {
     NULL_CHECK(cmd, "command buffer");
@@ -1121,7 +1131,7 @@ static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
 //               long as the queue of atomics on the hottest bin counter, which per-XCD counters cut (see reserve_bin_slots).
 //  MIRHI_TP_MAX_AREA (0 = off), MIRHI_TP_DENSITY, MIRHI_RASTER_TEAMS (1 / 2) override for A/B measurements.
 struct RasterMode { uint32_t tp_max_area, teams; bool tri_prog; };
-static RasterMode raster_mode(const RecordedPass& pass, size_t tiles) {
+static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool spread = false) {
     RasterMode m{0u, 1u, false};
     for (const DrawDesc& dd : pass.draws) m.tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
     PassParams key{};
@@ -1135,6 +1145,7 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles) {
     const bool mesh_only = !m.tri_prog && !pass.draws.empty();
     m.teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : (avg < 16 ? 2u : 1u);
     if (!(m.tp_max_area && mesh_only && !pass_is_ordered(pass)) || m.teams != 2u) m.teams = 1u;
+    if (spread && !getenv("MIRHI_RASTER_TEAMS")) m.teams = 1u;      // measured on an earlier submission of this command buffer (Workspace::spread)
     return m;
 }
 
@@ -1162,6 +1173,11 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
         cmd->last_stream = nullptr;
     }
+    {
+        uint64_t tris_now = 0;
+        for (auto& pass : cmd->passes) tris_now += pass.total_tris - pass.first_tri;
+        if (cmd->ws.spread && (tris_now > 2 * cmd->ws.spread_tris || 2 * tris_now < cmd->ws.spread_tris)) cmd->ws.spread = false;
+    }
     size_t total_draws = 0, max_tiles = 0, max_pages = 0, max_big = 0;
     struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };
     std::vector<Geo> geo;
@@ -1171,7 +1187,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         g.tiles_x = (ci->width + TILE - 1) / TILE; g.tiles_y = (ci->height + TILE - 1) / TILE;
         band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-        const RasterMode mode = raster_mode(pass, tiles);
+        const RasterMode mode = raster_mode(pass, tiles, cmd->ws.spread);
         g.xcd_bins = mode.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
         // A tile's bin holds up to BIN_TABLE_ROW pages (4096 records; eight lists of 512 with per-XCD bins) before it spills into
         // the big list, which EVERY tile walks -- the limit costs nothing until it is used: pages come out of one pool, sized by
@@ -1215,7 +1231,8 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     if ((r = grow(&w.bin_table, &w.bin_table_bytes, (max_tiles ? max_tiles : 1) * BIN_TABLE_ROW * sizeof(uint32_t))) != MIRHI_OK) return r;
     HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
     const size_t pool_pages = w.bin_pool_bytes / (BIN_PAGE_RECS * sizeof(BinRec));
-    w.grow_pool = false;
+    w.grow_pool = false; w.replan = false;
+    w.xcd_tiles_last = (!geo.empty() && geo.back().xcd_bins) ? geo.back().tiles_x * (geo.back().r1 - geo.back().r0) : 0u;
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
     size_t counter_bytes = w.counters_words * 4;
     const size_t want_words = 8 * max_tiles + 32 + 8 * POOL_COUNTER_STRIDE;   // bin counters (one per tile, or per tile and XCD), big-list counters, pool counters
@@ -1358,7 +1375,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
             P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
         {
-            const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0));
+            const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0), w.spread);
             P.tp_max_area = mode.tp_max_area;
             P.alpha_scope = pass_is_masked_plain(pass) ? 1u : 0u;
             P.raster_teams = mode.teams;
@@ -1462,7 +1479,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     if (fence && fence->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: fence belongs to another device");
     HIP_TRY(hipSetDevice(dev->ordinal));
     for (uint32_t i = 0; i < cmd_count; i++)
-        if (cmds[i]->ws.grow_pool && !getenv("MIRHI_POOL_PAGES")) {       // an earlier submission ran out of bin pages: a bigger pool, the same plan
+        if ((cmds[i]->ws.grow_pool && !getenv("MIRHI_POOL_PAGES")) || cmds[i]->ws.replan) {   // an earlier submission ran out of bin pages (a bigger pool, the same plan) or showed a spread-out mesh (one team)
             const mirhi_result rp = build_plan(cmds[i]);
             if (rp != MIRHI_OK) return rp;
         }
@@ -1592,6 +1609,7 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
             c->ws.grow_pool = true;
             if (c->ws.pool_scale < 64u) c->ws.pool_scale *= 2u;
         }
+        if (!c->ws.spread && c->ws.xcd_tiles_last && c->ws.status_host[2] > 2u * c->ws.xcd_tiles_last) { c->ws.spread = true; c->ws.replan = true; c->ws.spread_tris = c->plan_tris; }
         if (c->ws.status_host[0] & STATUS_PAGE_TIMEOUT)
             r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer bin page was never published; frame is incomplete");
         if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)

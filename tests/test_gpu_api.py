@@ -835,3 +835,22 @@ def _both(mirhi, oracle, device, scene):
     err = np.abs(out["color"][..., :4] - ref["rgba"]) / np.maximum(1.0, np.abs(ref["rgba"]))
     assert float(err.max()) < 1e-4
     return out, ref
+
+
+def test_two_team_mode_is_dropped_for_a_spread_out_mesh(mirhi, oracle, device, scenes):
+    """raster_mode picks the two-team mesh variant from the triangle count alone; a scope that then opens more than two list pages
+    per tile was spread over the frame, and the command buffer's plan is rebuilt with one team in front of its next submit -- same
+    pixels, and the statistic that showed it (dynamic bin pages) drops to the single-list figure."""
+    scene = scenes.heightfield_grid(40, 40, 640, 360)
+    res = mirhi.SceneResources(device, scene, want_prim=True)
+    res.render(); device.wait_idle()
+    first = device.stats().last_bin_pages
+    a = res.read()
+    res.render(); device.wait_idle()
+    second = device.stats().last_bin_pages
+    b = res.read()
+    ref = oracle.render(scene, want_bgra8=False)
+    assert np.array_equal(a["prim"], ref["prim"]) and np.array_equal(b["prim"], ref["prim"])
+    tiles = ((640 + 31) // 32) * ((360 + 31) // 32)
+    assert first > 2 * tiles and second < first // 4
+    res.destroy()
