@@ -7,7 +7,7 @@ m = ge.load_package()
 L = C.CDLL(m.LIB_PATH)
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 DANCER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dancer", "scene.gltf")
-make = {"dancer": lambda: m.scenes.gltf_model(DANCER), "dancer-tex": lambda: m.scenes.gltf_model(DANCER, textures=True), "tri1": lambda: m.scenes.random_triangles(1), "c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid, "c5": m.scenes.box_hall}[wl]
+make = {"dancer": lambda: m.scenes.gltf_model(DANCER), "dancer-tex": lambda: m.scenes.gltf_model(DANCER, textures=True), "tri1": lambda: m.scenes.random_triangles(1), "c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid, "c5": m.scenes.box_hall, "grid16": lambda: m.scenes.heightfield_grid(16, 16, 1920, 1080), "grid64": lambda: m.scenes.heightfield_grid(64, 64, 1920, 1080)}[wl]
 scene = make()
 dev = m.Device(0)
 res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
