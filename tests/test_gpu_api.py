@@ -854,3 +854,44 @@ def test_two_team_mode_is_dropped_for_a_spread_out_mesh(mirhi, oracle, device, s
     tiles = ((640 + 31) // 32) * ((360 + 31) // 32)
     assert first > 2 * tiles and second < first // 4
     res.destroy()
+
+
+def test_device_is_shared_by_host_threads(mirhi, oracle, device, scenes):
+    """`Device` is Send + Sync in the reference (device.rs:379-380) while command buffers are externally synchronised
+    (command.rs:48-51): four host threads, each with its own resources, command buffer, fence and queue lane, record, submit,
+    wait and read back concurrently on ONE device (ctypes drops the GIL inside every call).  Every frame of every thread must be the
+    oracle's, and creating / destroying objects under the other threads' submissions must not disturb them."""
+    import threading
+    seeds = [11, 12, 13, 14]
+    made = [scenes.random_triangles(400 + 50 * k, 320, 200, seed=s, rmin=3, rmax=30) for k, s in enumerate(seeds)]
+    refs = [oracle.render(sc, want_bgra8=False)["prim"] for sc in made]
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(12):
+                res = mirhi.SceneResources(device, made[k], want_prim=True)       # objects come and go while others render
+                res.cmd.set_queue_lane(k)
+                f = mirhi.Fence(device)
+                for _ in range(3):
+                    res.render(f)
+                    f.wait()
+                    f.reset()
+                    if not np.array_equal(res.read()["prim"], refs[k]):
+                        errors.append((k, it, "pixels"))
+                f.destroy()
+                res.destroy()
+        except Exception as e:        # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    device.set_queue_lanes(4)
+    try:
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        device.wait_idle()
+    finally:
+        device.set_queue_lanes(1)
+    assert not errors, errors[:5]
