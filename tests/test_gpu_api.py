@@ -895,3 +895,25 @@ def test_device_is_shared_by_host_threads(mirhi, oracle, device, scenes):
     finally:
         device.set_queue_lanes(1)
     assert not errors, errors[:5]
+
+
+def test_band_exchange_with_n_ranks_on_one_gpu(tmp_path):
+    """mirhi_comm_all_gather_bands needs N GPUs under the real RCCL.  Here N devices of one child process stand for the ranks and
+    tests/mock/mock_rccl.cpp (an in-process stand-in for the ten entry points the library resolves, loaded through
+    MIRHI_RCCL_LIBRARY) moves the bytes: band arithmetic, peers, byte counts, both algorithms, uneven and empty bands -- every
+    rank's frame must be the unsplit frame byte for byte.  (A child process: the library keeps the RCCL it loaded first.)"""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "libmock_rccl.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib,
+                           os.path.join(root, "tests", "mock", "mock_rccl.cpp")])
+    env = dict(os.environ)
+    env.pop("MIRHI_RCCL_LIBRARY", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "mock", "split_exchange_check.py"), lib], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert p.stdout.count(": ok") == 7, p.stdout[-3000:]
