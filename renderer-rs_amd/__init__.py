@@ -102,6 +102,7 @@ class GatherAlgo:
     DIRECT, BROADCAST = range(2)
 
 
+ABI_VERSION = 3                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
 COMM_ID_BYTES = 128
 
 
@@ -260,6 +261,8 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
+        if L.mirhi_abi_version() != ABI_VERSION:        # struct layouts (mirhi_pipeline_desc, ...) are this binding's: a stale library must not be driven with them
+            raise ImportError(f"{LIB_PATH} has ABI {L.mirhi_abi_version()}, this binding is written for ABI {ABI_VERSION}: rebuild (python __graft_entry__.py)")
         _lib = L
     return _lib
 

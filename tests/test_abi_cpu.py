@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(mirhi):
     assert len(declared_functions()) >= 60
     # the ctypes binding covers the same set
     assert set(mirhi._SIGNATURES) == set(declared_functions())
-    assert mirhi.lib().mirhi_abi_version() == 3
+    assert mirhi.lib().mirhi_abi_version() == 3 == mirhi.ABI_VERSION      # (the binding refuses a library of another ABI at load)
     assert int(re.search(r"#define MIRHI_ABI_VERSION (\d+)u", HEADER).group(1)) == 3
 
 
