@@ -21,6 +21,11 @@ pub struct DeviceStats {
 impl Device {
     /// `hip_ordinal`: the GPU this process owns (one process per GPU; LOCAL_RANK under torchrun-style launchers).
     pub fn new(hip_ordinal: i32) -> RhiResult<Arc<Self>> {
+        // the #[repr(C)] structs of mirhi-sys are one ABI's: a library of another one must not be driven with them
+        let abi = unsafe { mirhi_sys::mirhi_abi_version() };
+        if abi != mirhi_sys::MIRHI_ABI_VERSION {
+            return Err(crate::error::RhiError::LoadingError(format!("libmirhi.so has ABI {abi}, mirhi-sys was generated for ABI {}", mirhi_sys::MIRHI_ABI_VERSION)));
+        }
         let mut raw = std::ptr::null_mut();
         check(unsafe { mirhi_sys::mirhi_device_create(hip_ordinal, &mut raw) })?;
         Ok(Arc::new(Self { raw }))

@@ -194,6 +194,9 @@ static_assert(sizeof(Vertex) == 48, "vertex.rs:230-245");
 class Device {   // device.rs:61-77; shared as Arc<Device>
 public:
     static std::shared_ptr<Device> create(int ordinal = 0) {
+        // the structs of include/mirhi.h this translation unit was compiled against are one ABI's
+        if (mirhi_abi_version() != MIRHI_ABI_VERSION)
+            throw RhiError(MIRHI_ERR_LOADING, "Loading error: libmirhi.so has ABI " + std::to_string(mirhi_abi_version()) + ", built against ABI " + std::to_string(MIRHI_ABI_VERSION));
         mirhi_device* h = nullptr;
         check(mirhi_device_create(ordinal, &h));
         return std::shared_ptr<Device>(new Device(h));
