@@ -13,7 +13,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for w in c2 c3; do
+for w in c2 c3 c4 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > $out/bench_profile_pass_$w.json 2> $out/stats_$w.err
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/pmc_sq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_sq_$w.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_$w.err

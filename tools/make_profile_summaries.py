@@ -33,7 +33,7 @@ def means(pass_dir):
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
 
-for w in ("c2", "c3"):
+for w in ("c2", "c3", "c4", "c5"):
     shutil.copy(one(f"stats_{w}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{w}_rocprofv3_kernel_stats.csv"))
     line = last_json(os.path.join(src, f"bench_profile_pass_{w}.json"))
     json.dump(line, open(os.path.join(dst, f"{tag}_{w}_bench_profile_pass.json"), "w"), indent=1)
