@@ -103,6 +103,7 @@ struct mirhi_device {
     std::vector<mirhi_cmd*> unchecked;        // submitted since the last wait_idle: their status words are read there
     std::vector<mirhi_fence*> fences;         // live fences (guarded by mu): a command buffer that is destroyed or re-recorded
                                               //   while a fence still lists it hands its device status over first
+    std::vector<mirhi_cmd*> cmds;             // live command buffers (guarded by mu): lanes that go away are forgotten by all of them
     mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
     std::string deferred_msg;
     double total_ms[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
@@ -138,6 +139,10 @@ struct mirhi_pipeline {
 
 struct RecordedPass {
     mirhi_rendering_info info;
+    // what the attachments resolved to when the scope was recorded: two recordings are the same frame shape only if these agree
+    // (an image handle may be a new image at an old address)
+    struct Target { const uint8_t* ptr; uint32_t width, height, format; };
+    Target color_t{nullptr, 0, 0, 0}, depth_t{nullptr, 0, 0, 0}, prim_t{nullptr, 0, 0, 0};
     std::vector<DrawDesc> draws;
     std::vector<uint64_t> draw_vb_bytes;   // bytes of the bound vertex buffer range per draw (vertex pre-pass extent)
     uint32_t total_tris = 0;
@@ -151,8 +156,21 @@ struct RecordedPass {
     int32_t area[4] = {0, 0, 0, 0};
 };
 
+// Words of the counter block that never move (a re-recorded frame of another shape finds them where the last frame's kernels
+// left them, re-armed): the two big-list counters, the eight pool counters a cache line apart; the bin counters follow.
+constexpr uint32_t CTR_BIG = 0u, CTR_POOL = 32u, CTR_BINS = CTR_POOL + 8u * (uint32_t)POOL_COUNTER_STRIDE + 32u;
+
 struct Workspace {
-    DrawDesc* draws = nullptr; size_t draws_cap = 0;
+    // Parameter block: everything the kernels read as "parameters" -- two PassParams per scope (big-list counter parity 0 / 1), the
+    // draw descriptors, the vertex pre-pass jobs -- in ONE piece of fine-grained device memory that the host writes directly
+    // (stores over the PCIe BAR, 0.2 us per KB; tools/microbench/fence_latency.hip) and only when its bytes changed: re-recording
+    // an unchanged frame uploads nothing, a changed one costs a memcpy, and no copy command ever enters a stream.  `pshadow` is the
+    // host's copy of what the block holds (device memory is never read back over the BAR).
+    uint8_t* pblock = nullptr; size_t pblock_bytes = 0; bool pblock_direct = false;   // direct: host-writable; else uploads go through `pstage`
+    uint8_t* pstage = nullptr; size_t pstage_bytes = 0;                                // pinned staging for the fallback (hipMemcpyAsync on the lane)
+    std::vector<uint8_t> pshadow, pimage;                                              // what the block holds / what it should hold
+    size_t draws_off = 0, jobs_off = 0, draws_count = 0;
+    bool dirty = true;                                         // counters / page table not known to be in their idle state: cleared at the next plan
     BinRec* bin_pool = nullptr; size_t bin_pool_bytes = 0;     // pages of BIN_PAGE_RECS records: fixed first pages, then the dynamic ones
     uint32_t* bin_table = nullptr; size_t bin_table_bytes = 0; // [tiles][BIN_TABLE_ROW] page table, PAGE_EMPTY when idle
     uint32_t pool_scale = 1;                                   // doubled whenever a scope exhausted the pool (applied at the next submit)
@@ -168,10 +186,9 @@ struct Workspace {
     uint32_t xcd_tiles_last = 0;                               // tiles of the command buffer's last scope if it uses per-XCD bins, else 0
     uint32_t* counters = nullptr; size_t counters_words = 0;   // [8 * tiles] bin counts, two big-list counters, the pool counter
     BigRec* big_recs = nullptr; size_t big_recs_bytes = 0;
-    VsJob* vs_jobs = nullptr; size_t vs_jobs_bytes = 0;
     float* carry_depth = nullptr; size_t carry_depth_bytes = 0;   // depth hand-over between the segments of a scope without a depth attachment
     TriRec* ordered = nullptr; size_t ordered_bytes = 0;          // slot t = triangle t of an ordered segment (blending)
-    PassParams* params = nullptr; size_t params_bytes = 0;   // two copies per scope (big-list counter parity 0 / 1), read by the kernels
+    PassParams* params = nullptr;                            // = pblock: two copies per scope (big-list counter parity 0 / 1), read by the kernels
     uint8_t* vs_out = nullptr; size_t vs_out_bytes = 0;
     uint32_t* flat_color = nullptr; size_t flat_color_bytes = 0;
     uint32_t* prim_draw = nullptr; size_t prim_draw_bytes = 0;     // per primitive: its draw (scopes with several draws)
@@ -183,7 +200,7 @@ struct Workspace {
     // of the scopes' parameters that write it, so that the product kernels and parameters stay untouched
     uint32_t* stats_prim = nullptr; size_t stats_prim_bytes = 0;
     PassParams* stats_params = nullptr; size_t stats_params_bytes = 0; bool stats_params_valid = false;
-    size_t bytes() const { return draws_cap * sizeof(DrawDesc) + bin_pool_bytes + bin_table_bytes + counters_words * 4 + big_recs_bytes + vs_jobs_bytes + vs_out_bytes + flat_color_bytes; }
+    size_t bytes() const { return pblock_bytes + bin_pool_bytes + bin_table_bytes + counters_words * 4 + big_recs_bytes + vs_out_bytes + flat_color_bytes; }
 };
 
 enum CmdState { CMD_INITIAL = 0, CMD_RECORDING = 1, CMD_EXECUTABLE = 2 };
@@ -193,9 +210,18 @@ struct mirhi_cmd {
     CmdState state = CMD_INITIAL;
     uint32_t lane = 0;                     // submit stream of this command buffer (frames in flight overlap across lanes)
     hipStream_t last_stream = nullptr;     // the stream its last submission ran on (a batched submit runs on the first command buffer's lane)
+    bool pending = false;                  // submitted and not yet known to have finished (a fence wait / wait_idle clears it).  Vulkan forbids
+                                           //   re-recording a pending command buffer; this build synchronises instead -- the slow path a frame
+                                           //   loop that waits on its fences never takes
+    uint64_t submit_seq = 0;               // submissions so far (a fence remembers which one it saw)
     bool one_time = true;
     bool in_rendering = false;
     std::vector<RecordedPass> passes;
+    // Plan cache: the recording the current plan was built from.  A frame loop records the same frame again and again
+    // (renderer.rs:452-557); end() then finds plan, workspace and parameter block as they are and touches nothing.
+    std::vector<RecordedPass> planned;
+    bool plan_valid = false;
+    uint32_t plan_split_rank = 0, plan_split_world = 1;
     // current bindings (dynamic state + descriptors)
     mirhi_pipeline* pipeline = nullptr;
     mirhi_buffer* vb = nullptr; uint64_t vb_offset = 0;
@@ -220,6 +246,7 @@ struct mirhi_fence {
     bool signaled = false;      // host-visible signaled state
     bool pending = false;       // an event record is outstanding
     std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
+    std::vector<uint64_t> seqs;    //   and which submission of each it was (mirhi_cmd::submit_seq)
     mirhi_result deferred = MIRHI_OK;   // status handed over by a listed command buffer that was destroyed / re-recorded since
     std::string deferred_msg;
 };
@@ -312,6 +339,11 @@ extern "C" mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t
     if (lanes < 1 || lanes > 8) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lanes must be 1..8 (got %u)", lanes);
     mirhi_result r = sync_all_lanes(dev);
     if (r != MIRHI_OK) return r;
+    if (dev->lanes.size() > lanes) {
+        // (a command buffer must not keep the handle of a stream that is about to go: ADVICE r2, mirhi_cmd::last_stream)
+        std::lock_guard<std::mutex> lock(dev->mu);
+        for (mirhi_cmd* c : dev->cmds) { c->last_stream = nullptr; c->pending = false; }
+    }
     while (dev->lanes.size() > lanes) { (void)hipStreamDestroy(dev->lanes.back()); dev->lanes.pop_back(); }
     while (dev->lanes.size() < lanes) {
         hipStream_t st = nullptr;
@@ -673,13 +705,12 @@ extern "C" void mirhi_rendering_info_default(mirhi_rendering_info* i) {
 
 static void free_workspace(mirhi_cmd* c) {
     Workspace& w = c->ws;
-    if (w.draws) (void)hipFree(w.draws);
+    if (w.pblock) (void)hipFree(w.pblock);
+    if (w.pstage) (void)hipHostFree(w.pstage);
     if (w.bin_pool) (void)hipFree(w.bin_pool);
     if (w.bin_table) (void)hipFree(w.bin_table);
     if (w.counters) (void)hipFree(w.counters);
     if (w.big_recs) (void)hipFree(w.big_recs);
-    if (w.vs_jobs) (void)hipFree(w.vs_jobs);
-    if (w.params) (void)hipFree(w.params);
     if (w.carry_depth) (void)hipFree(w.carry_depth);
     if (w.ordered) (void)hipFree(w.ordered);
     if (w.vs_out) (void)hipFree(w.vs_out);
@@ -709,10 +740,10 @@ static void hand_over_status(mirhi_cmd* cmd) {
     const std::string msg = g_last_error;
     g_last_error = keep;
     for (mirhi_fence* f : dev->fences) {
-        auto it = std::remove(f->cmds.begin(), f->cmds.end(), cmd);
-        if (it == f->cmds.end()) continue;
-        f->cmds.erase(it, f->cmds.end());
-        if (rc != MIRHI_OK) { f->deferred = rc; f->deferred_msg = msg; }
+        bool had = false;
+        for (size_t i = f->cmds.size(); i-- > 0;)
+            if (f->cmds[i] == cmd) { f->cmds.erase(f->cmds.begin() + (ptrdiff_t)i); f->seqs.erase(f->seqs.begin() + (ptrdiff_t)i); had = true; }
+        if (had && rc != MIRHI_OK) { f->deferred = rc; f->deferred_msg = msg; }
     }
     if (was_unchecked) {
         u.erase(std::remove(u.begin(), u.end(), cmd), u.end());
@@ -726,6 +757,7 @@ extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
     if (!c) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
     c->dev = dev;
     c->lane = dev->next_lane++ % (uint32_t)dev->lanes.size();
+    { std::lock_guard<std::mutex> lock(dev->mu); dev->cmds.push_back(c); }
     dev->children++;
     *out = c;
     return MIRHI_OK;
@@ -735,6 +767,7 @@ extern "C" mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane) 
     if (lane >= cmd->dev->lanes.size()) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lane %u of %zu", lane, cmd->dev->lanes.size());
     if (cmd->last_stream) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
     HIP_TRY(hipStreamSynchronize(cmd->dev->lanes[cmd->lane < cmd->dev->lanes.size() ? cmd->lane : 0]));
+    cmd->pending = false;
     cmd->lane = lane;
     return MIRHI_OK;
 }
@@ -742,19 +775,20 @@ extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
     (void)sync_all_lanes(cmd->dev);
     hand_over_status(cmd);          // fences (and wait_idle) that still list this command buffer keep its device status
+    { std::lock_guard<std::mutex> lock(cmd->dev->mu); auto& v = cmd->dev->cmds; v.erase(std::remove(v.begin(), v.end(), cmd), v.end()); }
     free_workspace(cmd);
     cmd->dev->children--;
     delete cmd;
     return MIRHI_OK;
 }
 static void reset_recording(mirhi_cmd* c) {
-    c->passes.clear(); c->plan.clear(); c->plan_programs.clear(); c->plan_tris = 0;
+    // (the launch plan and the recording it was built from stay: end() compares the new recording with it -- see mirhi_cmd::planned)
+    c->passes.clear();
     c->in_rendering = false;
     c->pipeline = nullptr; c->vb = nullptr; c->ib = nullptr;
     for (auto& u : c->uniforms) u = {nullptr, 0, 0};
     for (auto& tx : c->textures) tx = nullptr;
     c->has_viewport = c->has_scissor = false;
-    c->ws.replan = false; c->ws.xcd_tiles_last = 0;     // (Workspace::spread survives: a frame loop records the same frame again)
 }
 static mirhi_result begin_common(mirhi_cmd* cmd, bool one_time) {
     NULL_CHECK(cmd, "command buffer");
@@ -796,6 +830,9 @@ extern "C" mirhi_result mirhi_cmd_begin_rendering(mirhi_cmd* cmd, const mirhi_re
     }
     RecordedPass p;
     p.info = *info;
+    p.color_t = {ci->ptr, ci->width, ci->height, (uint32_t)ci->format};
+    if (info->depth_image) p.depth_t = {info->depth_image->ptr, info->depth_image->width, info->depth_image->height, (uint32_t)info->depth_image->format};
+    if (info->prim_id_image) p.prim_t = {info->prim_id_image->ptr, info->prim_id_image->width, info->prim_id_image->height, (uint32_t)info->prim_id_image->format};
     if (info->render_area[2] <= 0 || info->render_area[3] <= 0) { p.area[0] = 0; p.area[1] = 0; p.area[2] = (int32_t)ci->width; p.area[3] = (int32_t)ci->height; }
     else memcpy(p.area, info->render_area, sizeof p.area);
     if (p.area[0] != 0 || p.area[1] != 0 || p.area[2] != (int32_t)ci->width || p.area[3] != (int32_t)ci->height)
@@ -916,6 +953,7 @@ static mirhi_result record_draw(mirhi_cmd* cmd, bool indexed, uint32_t count, ui
             RecordedPass& prev = cmd->passes.back();
             prev.carry_out = true;
             next.info = prev.info;
+            next.color_t = prev.color_t; next.depth_t = prev.depth_t; next.prim_t = prev.prim_t;
             memcpy(next.area, prev.area, sizeof next.area);
             next.info.color_load_op = MIRHI_LOAD_OP_LOAD;
             next.carry_in = true;
@@ -1149,30 +1187,118 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool sprea
     return m;
 }
 
-// Sizes the workspace of a recorded command buffer and builds its launch plan.  Runs at end() and again in front of a submit
-// when an earlier submission exhausted the bin pool (Workspace::grow_pool).
+// Sizes the workspace of a recorded command buffer and builds its launch plan.  Runs at end() -- unless the recording is the one the
+// current plan was built from -- and again in front of a submit when an earlier submission exhausted the bin pool
+// (Workspace::grow_pool) or showed a spread-out mesh (Workspace::replan).
 static mirhi_result build_plan(mirhi_cmd* cmd);
+
+static bool same_target(const RecordedPass::Target& a, const RecordedPass::Target& b) {
+    return a.ptr == b.ptr && a.width == b.width && a.height == b.height && a.format == b.format;
+}
+// Two recordings describe the same frame shape: same attachments, load / store ops, clear values, depth / blend state and, byte for
+// byte, the same draw descriptors (resolved device pointers, counts, viewport, scissor, state).  Buffer CONTENTS are not part of it:
+// the plan holds pointers, and a frame loop that rewrites its uniform buffer between frames records the same shape every time.
+static bool same_recording(const std::vector<RecordedPass>& a, const std::vector<RecordedPass>& b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++) {
+        const RecordedPass& x = a[i]; const RecordedPass& y = b[i];
+        if (!same_target(x.color_t, y.color_t) || !same_target(x.depth_t, y.depth_t) || !same_target(x.prim_t, y.prim_t)) return false;
+        if (x.info.color_load_op != y.info.color_load_op || x.info.color_store_op != y.info.color_store_op || x.info.depth_load_op != y.info.depth_load_op ||
+            x.info.depth_store_op != y.info.depth_store_op || memcmp(x.info.clear_color, y.info.clear_color, sizeof x.info.clear_color) != 0 ||
+            memcmp(&x.info.clear_depth, &y.info.clear_depth, sizeof(float)) != 0) return false;
+        if (x.total_tris != y.total_tris || x.first_tri != y.first_tri || x.key_set != y.key_set || x.depth_test != y.depth_test || x.depth_compare != y.depth_compare ||
+            x.depth_write != y.depth_write || x.frag_discard != y.frag_discard || memcmp(x.blend, y.blend, sizeof x.blend) != 0 ||
+            x.carry_in != y.carry_in || x.carry_out != y.carry_out || memcmp(x.area, y.area, sizeof x.area) != 0) return false;
+        if (x.draws.size() != y.draws.size() || x.draw_vb_bytes != y.draw_vb_bytes) return false;
+        if (!x.draws.empty() && memcmp(x.draws.data(), y.draws.data(), x.draws.size() * sizeof(DrawDesc)) != 0) return false;
+    }
+    return true;
+}
+
+// The workspace of a command buffer that may still be executing must not be touched: Vulkan forbids re-recording a pending command
+// buffer, this build waits for it.  A frame loop that waits on its in-flight fence first (renderer.rs:371-374) never waits here.
+static mirhi_result settle_pending(mirhi_cmd* cmd) {
+    if (!cmd->pending) return MIRHI_OK;
+    mirhi_device* dev = cmd->dev;
+    bool live = false;
+    for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
+    if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
+    cmd->pending = false;
+    return MIRHI_OK;
+}
+
 extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     REQUIRE_RECORDING(cmd);
     if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
+    mirhi_device* dev = cmd->dev;
+    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
+        same_recording(cmd->passes, cmd->planned)) {
+        // The frame recorded last time, recorded again: plan, workspace and parameter block are what they have to be.  No HIP call,
+        // no synchronisation, nothing uploaded; only the status words of the previous submission are handed over and re-armed.
+        mirhi_result r = settle_pending(cmd);
+        if (r != MIRHI_OK) return r;
+        if (cmd->ws.status_host && (cmd->ws.status_host[0] | cmd->ws.status_host[1] | cmd->ws.status_host[2])) {
+            hand_over_status(cmd);
+            cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0;
+        }
+        cmd->state = CMD_EXECUTABLE;
+        return MIRHI_OK;
+    }
     mirhi_result r = build_plan(cmd);
-    if (r != MIRHI_OK) return r;
+    if (r != MIRHI_OK) { cmd->plan_valid = false; return r; }
     cmd->state = CMD_EXECUTABLE;
     return MIRHI_OK;
 }
+
+// Host-written parameter block (Workspace::pblock).  Fine-grained device memory is mapped into the host's address space; if the
+// platform refuses either the allocation or the mapping, MIRHI_PARAM_UPLOAD=copy (or a failed allocation) selects plain device
+// memory filled by stream-ordered copies from a pinned staging buffer.
+static mirhi_result pblock_reserve(Workspace& w, size_t bytes) {
+    if (w.pblock && w.pblock_bytes >= bytes) return MIRHI_OK;
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    if (w.pblock) { (void)hipFree(w.pblock); w.pblock = nullptr; w.pblock_bytes = 0; }
+    if (w.pstage) { (void)hipHostFree(w.pstage); w.pstage = nullptr; w.pstage_bytes = 0; }
+    w.pshadow.clear();
+    void* p = nullptr;
+    const bool want_copy = getenv("MIRHI_PARAM_UPLOAD") && strcmp(getenv("MIRHI_PARAM_UPLOAD"), "copy") == 0;
+    hipError_t e = want_copy ? hipErrorNotSupported : hipExtMallocWithFlags(&p, want, hipDeviceMallocFinegrained);
+    w.pblock_direct = e == hipSuccess;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc(%zu) for the parameter block: %s", want, hipGetErrorString(e)); }
+        void* h = nullptr;
+        e = hipHostMalloc(&h, want, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipHostMalloc(%zu) for parameter staging: %s", want, hipGetErrorString(e)); }
+        w.pstage = (uint8_t*)h; w.pstage_bytes = want;
+    }
+    w.pblock = (uint8_t*)p; w.pblock_bytes = want;
+    return MIRHI_OK;
+}
+// Brings the block to `pimage`: nothing if it holds those bytes already.
+static mirhi_result pblock_commit(Workspace& w, hipStream_t stream) {
+    const size_t n = w.pimage.size();
+    if (w.pshadow.size() == n && (n == 0 || memcmp(w.pshadow.data(), w.pimage.data(), n) == 0)) return MIRHI_OK;
+    if (n) {
+        if (w.pblock_direct) {
+            memcpy(w.pblock, w.pimage.data(), n);          // write-combined stores over the BAR ...
+            __builtin_ia32_sfence();                         // ... out of the write-combining buffers before any launch rings a doorbell
+        } else {
+            memcpy(w.pstage, w.pimage.data(), n);
+            HIP_TRY(hipMemcpyAsync(w.pblock, w.pstage, n, hipMemcpyHostToDevice, stream));
+        }
+    }
+    w.pshadow = w.pimage;
+    return MIRHI_OK;
+}
+
 static mirhi_result build_plan(mirhi_cmd* cmd) {
     mirhi_device* dev = cmd->dev;
     HIP_TRY(hipSetDevice(dev->ordinal));
-    // the workspace may still be in use by an earlier submission of this command buffer
     if (cmd->lane >= dev->lanes.size()) cmd->lane = 0;
     hipStream_t stream = dev->lanes[cmd->lane];
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (cmd->last_stream && cmd->last_stream != stream) {
-        bool live = false;
-        for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
-        if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
-        cmd->last_stream = nullptr;
-    }
+    cmd->plan_valid = false;
+    { mirhi_result rs = settle_pending(cmd); if (rs != MIRHI_OK) return rs; }
     {
         uint64_t tris_now = 0;
         for (auto& pass : cmd->passes) tris_now += pass.total_tris - pass.first_tri;
@@ -1182,9 +1308,9 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };
     std::vector<Geo> geo;
     for (auto& pass : cmd->passes) {
-        const mirhi_image* ci = pass.info.color_image;
+        const RecordedPass::Target& ci = pass.color_t;
         Geo g;
-        g.tiles_x = (ci->width + TILE - 1) / TILE; g.tiles_y = (ci->height + TILE - 1) / TILE;
+        g.tiles_x = (ci.width + TILE - 1) / TILE; g.tiles_y = (ci.height + TILE - 1) / TILE;
         band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
         const RasterMode mode = raster_mode(pass, tiles, cmd->ws.spread);
@@ -1224,42 +1350,56 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     }
     Workspace& w = cmd->ws;
     mirhi_result r;
-    size_t draws_bytes = w.draws_cap * sizeof(DrawDesc);
-    if ((r = grow(&w.draws, &draws_bytes, (total_draws ? total_draws : 1) * sizeof(DrawDesc))) != MIRHI_OK) return r;
-    w.draws_cap = draws_bytes / sizeof(DrawDesc);
+    // Buffers only ever grow, and a frame loop's do not: the steady state allocates nothing.  Counters and page table are cleared
+    // when they are new (or after a frame that went wrong on the device: Workspace::dirty) -- never otherwise: every kernel leaves
+    // them re-armed (raster_body: bin counters, table rows, pool counters, the other parity's big-list counter), and the fixed
+    // words of the counter block do not move when the tile count changes (CTR_*).
     if ((r = grow(&w.bin_pool, &w.bin_pool_bytes, (max_pages ? max_pages : 1) * BIN_PAGE_RECS * sizeof(BinRec))) != MIRHI_OK) return r;
-    if ((r = grow(&w.bin_table, &w.bin_table_bytes, (max_tiles ? max_tiles : 1) * BIN_TABLE_ROW * sizeof(uint32_t))) != MIRHI_OK) return r;
-    HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
+    {
+        const bool had = w.bin_table != nullptr && w.bin_table_bytes >= (max_tiles ? max_tiles : 1) * BIN_TABLE_ROW * sizeof(uint32_t);
+        if ((r = grow(&w.bin_table, &w.bin_table_bytes, (max_tiles ? max_tiles : 1) * BIN_TABLE_ROW * sizeof(uint32_t))) != MIRHI_OK) return r;
+        if (!had) w.dirty = true;
+    }
     const size_t pool_pages = w.bin_pool_bytes / (BIN_PAGE_RECS * sizeof(BinRec));
-    w.grow_pool = false; w.replan = false;
     w.xcd_tiles_last = (!geo.empty() && geo.back().xcd_bins) ? geo.back().tiles_x * (geo.back().r1 - geo.back().r0) : 0u;
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
-    size_t counter_bytes = w.counters_words * 4;
-    const size_t want_words = 8 * max_tiles + 32 + 8 * POOL_COUNTER_STRIDE;   // bin counters (one per tile, or per tile and XCD), big-list counters, pool counters
-    const bool fresh = !(w.counters && counter_bytes >= want_words * 4);
-    if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
-    w.counters_words = counter_bytes / 4;
-    (void)fresh;
-    HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, stream));
+    {
+        size_t counter_bytes = w.counters_words * 4;
+        const size_t want_words = CTR_BINS + 8 * max_tiles;   // fixed words (big-list and pool counters), then the bin counters (one per tile, or per tile and XCD)
+        const bool had = w.counters && counter_bytes >= want_words * 4;
+        if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
+        w.counters_words = counter_bytes / 4;
+        if (!had) w.dirty = true;
+    }
+    if (getenv("MIRHI_ALWAYS_CLEAR")) w.dirty = true;             // (A/B runs: the round-2 behaviour, two memsets per recording)
     if (!w.status_host) {
         HIP_TRY(hipHostMalloc((void**)&w.status_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(hipHostGetDevicePointer((void**)&w.status_dev, w.status_host, 0));
     }
     w.stats_params_valid = false;
-    hand_over_status(cmd);          // an earlier submission's status is not lost to the re-arm below
+    hand_over_status(cmd);          // an earlier submission's status is not lost to the re-arm below (and may ask for a bigger pool: before the flags are cleared)
+    w.grow_pool = false; w.replan = false;
     w.status_host[0] = 0; w.status_host[1] = 0; w.status_host[2] = 0;
-    w.big_counts = w.counters + 8 * max_tiles;
-    w.parity = 0;
+    w.big_counts = w.counters + CTR_BIG;
+    if (w.dirty) {
+        HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
+        HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, stream));
+        w.parity = 0;
+        w.dirty = false;
+        cmd->last_stream = stream; cmd->pending = true;      // (a submit on another stream -- a batched one -- waits for the clears)
+    }
 
     // vertex pre-pass jobs: one per distinct (vertex range, camera, object, program class) of each scope
     struct HostJob { VsJob j; size_t out_off; };
     std::vector<std::vector<HostJob>> pass_jobs(cmd->passes.size());
+    std::vector<std::vector<DrawDesc>> pass_draws(cmd->passes.size());      // the recorded descriptors stay as recorded (plan cache); these get the plan's fields
     size_t vs_bytes_max = 0, jobs_total = 0;
     for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
         RecordedPass& pass = cmd->passes[pi];
+        pass_draws[pi] = pass.draws;
         size_t off = 0; uint32_t slots = 0;
         for (size_t di = 0; di < pass.draws.size(); di++) {
-            DrawDesc& dd = pass.draws[di];
+            DrawDesc& dd = pass_draws[pi][di];
             dd.vs_words = 0; dd.vs_out = nullptr;
             if (dd.program == MIRHI_PROGRAM_TRIANGLE) continue;
             const uint32_t words = dd.program == MIRHI_PROGRAM_MODEL ? 3u : 5u;
@@ -1286,12 +1426,11 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         jobs_total += pass_jobs[pi].size();
     }
     if ((r = grow(&w.vs_out, &w.vs_out_bytes, vs_bytes_max ? vs_bytes_max : 256)) != MIRHI_OK) return r;
-    if ((r = grow(&w.vs_jobs, &w.vs_jobs_bytes, (jobs_total ? jobs_total : 1) * sizeof(VsJob))) != MIRHI_OK) return r;
     {
         size_t carry = 0;
         for (auto& pass : cmd->passes)
-            if ((pass.carry_in || pass.carry_out) && !pass.info.depth_image) {
-                const size_t need = (size_t)pass.info.color_image->width * pass.info.color_image->height * 4;
+            if ((pass.carry_in || pass.carry_out) && !pass.depth_t.ptr) {
+                const size_t need = (size_t)pass.color_t.width * pass.color_t.height * 4;
                 if (need > carry) carry = need;
             }
         if (carry && (r = grow(&w.carry_depth, &w.carry_depth_bytes, carry)) != MIRHI_OK) return r;
@@ -1302,14 +1441,11 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
             if (pass_is_ordered(pass)) { const size_t need = (size_t)(pass.total_tris - pass.first_tri) * sizeof(TriRec); if (need > ord) ord = need; }
         if (ord && (r = grow(&w.ordered, &w.ordered_bytes, ord)) != MIRHI_OK) return r;
     }
-    if ((r = grow(&w.params, &w.params_bytes, (cmd->passes.size() ? cmd->passes.size() : 1) * 2 * sizeof(PassParams))) != MIRHI_OK) return r;
-    std::vector<VsJob> all_jobs;
-    all_jobs.reserve(jobs_total);
     size_t flat_tris = 0;
     for (auto& pass : cmd->passes) {
         bool tri_prog = false;
         for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
-        if (tri_prog && pass.info.color_image->format == MIRHI_FORMAT_B8G8R8A8_SRGB && pass.total_tris > flat_tris) flat_tris = pass.total_tris;
+        if (tri_prog && pass.color_t.format == MIRHI_FORMAT_B8G8R8A8_SRGB && pass.total_tris > flat_tris) flat_tris = pass.total_tris;
     }
     if (flat_tris && (r = grow(&w.flat_color, &w.flat_color_bytes, flat_tris * 4)) != MIRHI_OK) return r;
     {
@@ -1318,21 +1454,31 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
             if (pass.draws.size() > 1 && (size_t)(pass.total_tris - pass.first_tri) > pd) pd = pass.total_tris - pass.first_tri;
         if (pd && (r = grow(&w.prim_draw, &w.prim_draw_bytes, pd * 4)) != MIRHI_OK) return r;
     }
+    // the parameter block: [2 x PassParams per scope][draw descriptors][vertex jobs]
+    const size_t params_bytes = cmd->passes.size() * 2 * sizeof(PassParams);
+    w.draws_off = (params_bytes + 255) & ~(size_t)255;
+    w.jobs_off = (w.draws_off + total_draws * sizeof(DrawDesc) + 255) & ~(size_t)255;
+    const size_t block_bytes = w.jobs_off + jobs_total * sizeof(VsJob);
+    if ((r = pblock_reserve(w, block_bytes ? block_bytes : 256)) != MIRHI_OK) return r;
+    w.params = reinterpret_cast<PassParams*>(w.pblock);
+    DrawDesc* const dev_draws = reinterpret_cast<DrawDesc*>(w.pblock + w.draws_off);
+    VsJob* const dev_jobs = reinterpret_cast<VsJob*>(w.pblock + w.jobs_off);
+    w.pimage.assign(block_bytes, 0);
+    w.draws_count = total_draws;
 
-    // upload draw descriptors, build per-pass parameters
-    std::vector<DrawDesc> all;
-    all.reserve(total_draws);
+    size_t draws_done = 0, jobs_done = 0;
     cmd->plan.clear(); cmd->plan_programs.clear(); cmd->plan_tris = 0;
     for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
         RecordedPass& pass = cmd->passes[pi];
+        std::vector<DrawDesc>& draws = pass_draws[pi];
         const Geo& g = geo[pi];
-        const mirhi_image* ci = pass.info.color_image;
+        const RecordedPass::Target& ci = pass.color_t;
         PassParams P;
         memset(&P, 0, sizeof P);
-        P.width = ci->width; P.height = ci->height;
+        P.width = ci.width; P.height = ci.height;
         P.tiles_x = g.tiles_x; P.tiles_y = g.tiles_y; P.tile_row_begin = g.r0; P.tile_row_end = g.r1;
-        P.num_draws = (uint32_t)pass.draws.size(); P.total_tris = pass.total_tris;
-        P.draws = w.draws + all.size();
+        P.num_draws = (uint32_t)draws.size(); P.total_tris = pass.total_tris;
+        P.draws = dev_draws + draws_done;
         depth_key_setup(P, pass);
         if (pass_is_ordered(pass)) {
             P.ordered_recs = w.ordered; P.ordered_first = pass.first_tri; P.ordered_count = pass.total_tris - pass.first_tri;
@@ -1348,10 +1494,10 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
                              ((uint32_t)std::nearbyint(sat(P.clear_color[3]) * 255.0f) << 24);
         }
         P.color_load = pass.info.color_load_op == MIRHI_LOAD_OP_LOAD ? 1u : 0u;
-        P.color_format = (uint32_t)ci->format;
-        P.color = ci->ptr;
-        if (pass.info.depth_image) {
-            P.depth = (float*)pass.info.depth_image->ptr;
+        P.color_format = ci.format;
+        P.color = const_cast<uint8_t*>(ci.ptr);
+        if (pass.depth_t.ptr) {
+            P.depth = (float*)const_cast<uint8_t*>(pass.depth_t.ptr);
             P.depth_load = pass.info.depth_load_op == MIRHI_LOAD_OP_LOAD ? 1u : 0u;
             P.depth_store = pass.info.depth_store_op == MIRHI_STORE_OP_STORE ? 1u : 0u;
         } else if (pass.carry_in || pass.carry_out) {
@@ -1359,20 +1505,20 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
         }
         if (pass.carry_in) P.depth_load = 1u;
         if (pass.carry_out) P.depth_store = 1u;
-        P.prim_out = pass.info.prim_id_image ? (uint32_t*)pass.info.prim_id_image->ptr : nullptr;
-        P.bin_pool = w.bin_pool; P.bin_count = w.counters; P.bin_cap = g.bin_cap;
-        P.bin_table = w.bin_table; P.pool_next = w.big_counts + 32;
+        P.prim_out = (uint32_t*)const_cast<uint8_t*>(pass.prim_t.ptr);
+        P.bin_pool = w.bin_pool; P.bin_count = w.counters + CTR_BINS; P.bin_cap = g.bin_cap;
+        P.bin_table = w.bin_table; P.pool_next = w.counters + CTR_POOL;
         P.pool_dyn_base = g.fixed_pages; P.pool_dyn_pages = (uint32_t)((pool_pages - g.fixed_pages) / 8);      // per XCD
         P.fixed_recs = g.fixed_per_tile * BIN_PAGE_RECS;
         P.big_recs = w.big_recs; P.big_count = w.big_counts; P.big_count_next = w.big_counts + 1; P.big_cap = g.big_cap;
         P.status = w.status_dev;
         P.frag_stats = dev->frag_stats;
         P.first_prim = pass.first_tri;
-        P.prim_draw = pass.draws.size() > 1 ? w.prim_draw : nullptr;
+        P.prim_draw = draws.size() > 1 ? w.prim_draw : nullptr;
         {
             bool tri_prog = false;
-            for (const DrawDesc& dd : pass.draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
-            P.flat_color = (tri_prog && ci->format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
+            for (const DrawDesc& dd : draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
+            P.flat_color = (tri_prog && ci.format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
         {
             const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0), w.spread);
@@ -1383,46 +1529,43 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
             P.count_stride = g.xcd_bins ? (uint32_t)max_tiles : 0u;
         }
         P.xcd_swizzle = getenv("MIRHI_XCD_RUN") ? (uint32_t)atoi(getenv("MIRHI_XCD_RUN")) : 1u;
-        P.vs_jobs = w.vs_jobs + all_jobs.size();
+        P.vs_jobs = dev_jobs + jobs_done;
         P.num_vs_jobs = (uint32_t)pass_jobs[pi].size();
         P.vs_total_slots = 0;
-        for (HostJob& hj : pass_jobs[pi]) {
+        VsJob* const img_jobs = reinterpret_cast<VsJob*>(w.pimage.data() + w.jobs_off) + jobs_done;
+        for (size_t j = 0; j < pass_jobs[pi].size(); j++) {
+            HostJob& hj = pass_jobs[pi][j];
             hj.j.out = w.vs_out + hj.out_off;
             P.vs_total_slots = hj.j.slot_base + (hj.j.count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS;
-            all_jobs.push_back(hj.j);
+            img_jobs[j] = hj.j;
         }
-        for (DrawDesc& dd : pass.draws)
+        jobs_done += pass_jobs[pi].size();
+        for (DrawDesc& dd : draws)
             if (dd.vs_words) dd.vs_out = w.vs_out + ((size_t)(uintptr_t)dd.vs_out - 1);
         uint32_t slots = 0;
-        for (DrawDesc& dd : pass.draws) { dd.slot_base = slots; slots += (dd.tri_count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS; }
+        for (DrawDesc& dd : draws) { dd.slot_base = slots; slots += (dd.tri_count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS; }
         P.total_slots = slots;
-        all.insert(all.end(), pass.draws.begin(), pass.draws.end());
+        if (!draws.empty()) memcpy(w.pimage.data() + w.draws_off + draws_done * sizeof(DrawDesc), draws.data(), draws.size() * sizeof(DrawDesc));
+        draws_done += draws.size();
         cmd->plan.push_back(P);
         uint32_t progs = 0;
-        for (const DrawDesc& dd : pass.draws) progs |= dd.program == 0 ? 1u : ((dd.program == MIRHI_PROGRAM_MODEL_PBR || dd.tex_any_mips || dd.tex_srgb) ? 4u : 2u);
+        for (const DrawDesc& dd : draws) progs |= dd.program == 0 ? 1u : ((dd.program == MIRHI_PROGRAM_MODEL_PBR || dd.tex_any_mips || dd.tex_srgb) ? 4u : 2u);
         cmd->plan_programs.push_back(progs ? progs : 1u);
         cmd->plan_tris += pass.total_tris - pass.first_tri;
-    }
-    if (!all.empty()) {
-        HIP_TRY(hipMemcpyAsync(w.draws, all.data(), all.size() * sizeof(DrawDesc), hipMemcpyHostToDevice, stream));
-    }
-    if (!all_jobs.empty()) {
-        HIP_TRY(hipMemcpyAsync(w.vs_jobs, all_jobs.data(), all_jobs.size() * sizeof(VsJob), hipMemcpyHostToDevice, stream));
-    }
-    // the kernels read their parameters from device memory: copy 2*pi + parity of scope pi appends large triangles to
-    // counter `parity` and re-arms the other one for the scope that follows on this workspace
-    std::vector<PassParams> dev_params;
-    for (const PassParams& P0 : cmd->plan) {
+        // the kernels read their parameters from the block: copy 2*pi + parity of scope pi appends large triangles to counter
+        // `parity` and re-arms the other one for the scope that follows on this workspace
         for (uint32_t parity = 0; parity < 2; parity++) {
-            PassParams P = P0;
-            P.big_count = w.big_counts + parity;
-            P.big_count_next = w.big_counts + (parity ^ 1u);
-            dev_params.push_back(P);
+            PassParams Q = P;
+            Q.big_count = w.big_counts + parity;
+            Q.big_count_next = w.big_counts + (parity ^ 1u);
+            memcpy(w.pimage.data() + (2 * pi + parity) * sizeof(PassParams), &Q, sizeof Q);
         }
     }
-    if (!dev_params.empty())
-        HIP_TRY(hipMemcpyAsync(w.params, dev_params.data(), dev_params.size() * sizeof(PassParams), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if ((r = pblock_commit(w, stream)) != MIRHI_OK) return r;
+    if (!w.pblock_direct) { cmd->last_stream = stream; cmd->pending = true; }     // (the copy is in the lane's stream)
+    cmd->planned = cmd->passes;
+    cmd->plan_split_rank = dev->split_rank; cmd->plan_split_world = dev->split_world;
+    cmd->plan_valid = true;
     dev->stats.workspace_bytes = w.bytes();
     return MIRHI_OK;
 }
@@ -1487,21 +1630,43 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
     // Batched form: the command buffers of one submit, when each is one plain rendering scope of the same shape and kernel variants
     // (the frames of a frame loop), share one vertex, one geometry and one raster launch on the first one's queue lane -- the
     // ramp-up and drain of a kernel and the latency chain of the geometry kernel are paid once per batch, not once per frame.
+    // Only frames that are independent of each other may share a launch: every scope clears (no LOAD of colour or depth -- what it
+    // would load might be written by another scope of the batch), no two scopes share a colour, depth or primitive-id attachment, and
+    // all command buffers sit on the first one's queue lane (so the batch keeps their order against earlier work of that lane).
+    // Anything else runs command buffer by command buffer, in submission order on each lane.
     bool batched = cmd_count >= 2 && cmd_count <= (uint32_t)MAX_BATCH && dev->profiling == 0 && !getenv("MIRHI_NO_BATCH");
     for (uint32_t i = 0; batched && i < cmd_count; i++) {
         const mirhi_cmd* c = cmds[i];
-        batched = c->plan.size() == 1 && raster_batchable(c->plan[0]) &&
+        batched = c->plan.size() == 1 && raster_batchable(c->plan[0]) && c->lane == cmds[0]->lane &&
                   raster_variant_key(c->plan[0], c->plan_programs[0]) == raster_variant_key(cmds[0]->plan[0], cmds[0]->plan_programs[0]) &&
-                  c->plan_programs[0] == cmds[0]->plan_programs[0];
-        for (uint32_t j = 0; batched && j < i; j++) batched = cmds[j] != c;          // (the same command buffer twice: one after the other)
+                  c->plan_programs[0] == cmds[0]->plan_programs[0] && !c->plan[0].color_load && !c->plan[0].depth_load;
+        for (uint32_t j = 0; batched && j < i; j++) {
+            const PassParams& A = cmds[j]->plan[0]; const PassParams& B = c->plan[0];
+            batched = cmds[j] != c && A.color != B.color && !(A.depth && A.depth == B.depth) && !(A.prim_out && A.prim_out == B.prim_out);
+        }
+    }
+    // The fence rides on the submit's last dispatch (its completion signal: hipExtLaunchKernelGGL stop event) when there is one and
+    // everything of the submit runs on one stream -- an event RECORD is a command of its own in the stream: 4.5 us of stream time and
+    // a round trip of 12-14 us against 6-9 us (tools/microbench/fence_latency.hip).
+    hipEvent_t fence_stop = nullptr;
+    bool fence_attached = false;
+    if (fence) {
+        if (!fence->event) HIP_TRY(hipEventCreate(&fence->event));
+        bool one_stream = cmd_count >= 1 && dev->profiling == 0 && !getenv("MIRHI_FENCE_RECORD");
+        for (uint32_t i = 1; one_stream && i < cmd_count && !batched; i++) one_stream = cmds[i]->lane == cmds[0]->lane;
+        if (one_stream) {
+            const mirhi_cmd* last = cmds[cmd_count - 1];
+            const bool has_launch = !last->plan.empty() && last->plan.back().tile_row_end > last->plan.back().tile_row_begin && last->plan.back().tiles_x != 0u;
+            if (has_launch) fence_stop = fence->event;
+        }
     }
     if (batched) {
         hipStream_t stream = dev->lanes[cmds[0]->lane < dev->lanes.size() ? cmds[0]->lane : 0];
         const PassParams* P[MAX_BATCH]; const PassParams* dp[MAX_BATCH]; uint32_t* big[MAX_BATCH];
         for (uint32_t i = 0; i < cmd_count; i++) {
             mirhi_cmd* c = cmds[i];
-            if (c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
-            c->last_stream = stream;
+            if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
+            c->last_stream = stream; c->pending = true; c->submit_seq++;
             if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
             P[i] = &c->plan[0];
             dp[i] = c->ws.params + c->ws.parity;
@@ -1512,13 +1677,14 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         }
         HIP_TRY(launch_vertex_batch(P, dp, cmd_count, stream));
         HIP_TRY(launch_geometry_batch(P, dp, cmd_count, stream));
-        HIP_TRY(launch_raster_batch(P, dp, big, cmd_count, cmds[0]->plan_programs[0], stream));
+        HIP_TRY(launch_raster_batch(P, dp, big, cmd_count, cmds[0]->plan_programs[0], stream, fence_stop));
+        fence_attached = fence_stop != nullptr;
     }
     for (uint32_t i = 0; !batched && i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
-        if (c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
-        c->last_stream = stream;
+        if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
+        c->last_stream = stream; c->pending = true; c->submit_seq++;
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
             const PassParams& P = c->plan[pi];
@@ -1561,6 +1727,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
                 }
             }
             if (timed && has_tiles) { mirhi_result r = timing_begin(dev, MIRHI_KERNEL_RASTER, c->lane, &tr); if (r != MIRHI_OK) return r; }
+            if (fence_stop && i + 1 == cmd_count && pi + 1 == c->plan.size() && has_tiles) { tr.stop = fence_stop; fence_attached = true; }   // (never together with `timed`)
             HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr));
             if (winners) HIP_TRY(launch_winner_count(winners, P.width * P.height, dev->frag_stats, stream));
             dev->stats.frames_submitted++;
@@ -1568,20 +1735,23 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         }
     }
     if (fence) {
-        if (!fence->event) HIP_TRY(hipEventCreateWithFlags(&fence->event, hipEventDisableTiming));
-        // the fence follows the last command buffer's lane and waits for the other lanes used by this submit
-        hipStream_t fstream = cmd_count ? cmds[cmd_count - 1]->last_stream : dev->stream;
-        for (uint32_t i = 0; i + 1 < cmd_count; i++) {
-            hipStream_t other = cmds[i]->last_stream;
-            if (other != fstream) {
-                if (!fence->join) HIP_TRY(hipEventCreateWithFlags(&fence->join, hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(fence->join, other));
-                HIP_TRY(hipStreamWaitEvent(fstream, fence->join, 0));
+        if (!fence_attached) {
+            // the fence follows the last command buffer's lane and waits for the other lanes used by this submit
+            hipStream_t fstream = cmd_count ? cmds[cmd_count - 1]->last_stream : dev->stream;
+            for (uint32_t i = 0; i + 1 < cmd_count; i++) {
+                hipStream_t other = cmds[i]->last_stream;
+                if (other != fstream) {
+                    if (!fence->join) HIP_TRY(hipEventCreateWithFlags(&fence->join, hipEventDisableTiming));
+                    HIP_TRY(hipEventRecord(fence->join, other));
+                    HIP_TRY(hipStreamWaitEvent(fstream, fence->join, 0));
+                }
             }
+            HIP_TRY(hipEventRecord(fence->event, fstream));
         }
-        HIP_TRY(hipEventRecord(fence->event, fstream));
         fence->pending = true; fence->signaled = false;
         fence->cmds.assign(cmds, cmds + cmd_count);
+        fence->seqs.resize(cmd_count);
+        for (uint32_t i = 0; i < cmd_count; i++) fence->seqs[i] = cmds[i]->submit_seq;
         fence->deferred = MIRHI_OK; fence->deferred_msg.clear();
     }
     return MIRHI_OK;
@@ -1610,6 +1780,7 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
             if (c->ws.pool_scale < 64u) c->ws.pool_scale *= 2u;
         }
         if (!c->ws.spread && c->ws.xcd_tiles_last && c->ws.status_host[2] > 2u * c->ws.xcd_tiles_last) { c->ws.spread = true; c->ws.replan = true; c->ws.spread_tris = c->plan_tris; }
+        if (c->ws.status_host[0] & (STATUS_PAGE_TIMEOUT | STATUS_BIG_OVERFLOW)) c->ws.dirty = true;     // counters / page table are cleared before the next frame
         if (c->ws.status_host[0] & STATUS_PAGE_TIMEOUT)
             r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer bin page was never published; frame is incomplete");
         if (c->ws.status_host[0] & STATUS_ALPHA_TEST_TEXTURED)
@@ -1624,6 +1795,7 @@ static mirhi_result check_status_words(mirhi_device* dev) {
     mirhi_result r = MIRHI_OK;
     for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
     dev->unchecked.clear();
+    for (mirhi_cmd* c : dev->cmds) c->pending = false;       // (called with every lane synchronised)
     if (dev->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = dev->deferred; g_last_error = dev->deferred_msg; } dev->deferred = MIRHI_OK; dev->deferred_msg.clear(); }
     return r;
 }
@@ -1632,13 +1804,17 @@ static mirhi_result fence_complete(mirhi_fence* f) {
     mirhi_result r = MIRHI_OK;
     {
         std::lock_guard<std::mutex> lock(f->dev->mu);          // what a fence has reported is not reported again by wait_idle
-        for (mirhi_cmd* c : f->cmds) {
+        for (size_t i = 0; i < f->cmds.size(); i++) {
+            mirhi_cmd* c = f->cmds[i];
             const mirhi_result rc = status_of(f->dev, c); if (rc != MIRHI_OK) r = rc;
-            auto& u = f->dev->unchecked;
-            u.erase(std::remove(u.begin(), u.end(), c), u.end());
+            if (c->submit_seq == f->seqs[i]) {              // (a later submission of the same command buffer is still its own fence's business)
+                c->pending = false;
+                auto& u = f->dev->unchecked;
+                u.erase(std::remove(u.begin(), u.end(), c), u.end());
+            }
         }
     }
-    f->cmds.clear();
+    f->cmds.clear(); f->seqs.clear();
     if (f->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = f->deferred; g_last_error = f->deferred_msg; } f->deferred = MIRHI_OK; f->deferred_msg.clear(); }
     return r;
 }
@@ -1653,6 +1829,15 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
     }
     HIP_TRY(hipSetDevice(f->dev->ordinal));
     if (timeout_ns == UINT64_MAX) {
+        // a frame loop's fence is due within microseconds: poll (60 ns per query) for a while before blocking in the runtime
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+        for (uint32_t it = 0;; it++) {
+            hipError_t e = hipEventQuery(f->event);
+            if (e == hipSuccess) return fence_complete(f);
+            if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");
+            (void)hipGetLastError();
+            if ((it & 63u) == 63u && std::chrono::steady_clock::now() >= spin_until) break;
+        }
         HIP_TRY(hipEventSynchronize(f->event));
         return fence_complete(f);
     }
@@ -1912,18 +2097,24 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
     HIP_TRY(hipEventRecord(comm->ready, lane));              // the exchange starts behind the frame's raster kernel ...
     HIP_TRY(hipStreamWaitEvent(stream, comm->ready, 0));
     RCCL_TRY(R, R->GroupStart());
-    for (uint32_t r = 0; r < comm->world; r++) {
+    // Inside the group nothing returns early: a failing call must not leave the thread's RCCL group open (every later RCCL call of
+    // this thread, torch.distributed's included, would queue into a group that never ends).  The first error is kept, the group is
+    // closed, and only a successful exchange makes the lane wait for it.
+    ncclResult_t first = ncclSuccess; const char* what = "";
+    auto note = [&](ncclResult_t rc, const char* call) { if (rc != ncclSuccess && first == ncclSuccess) { first = rc; what = call; } };
+    for (uint32_t r = 0; r < comm->world && first == ncclSuccess; r++) {
         size_t off, bytes;
         band(r, &off, &bytes);
         if (algo == MIRHI_GATHER_BROADCAST) {
-            if (bytes) RCCL_TRY(R, R->Broadcast(frame->ptr + off, frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream));
+            if (bytes) note(R->Broadcast(frame->ptr + off, frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream), "ncclBroadcast");
             continue;
         }
         if (r == comm->rank) continue;
-        if (my_bytes) RCCL_TRY(R, R->Send(frame->ptr + my_off, my_bytes, ncclUint8, (int)r, comm->comm, stream));
-        if (bytes) RCCL_TRY(R, R->Recv(frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream));
+        if (my_bytes) note(R->Send(frame->ptr + my_off, my_bytes, ncclUint8, (int)r, comm->comm, stream), "ncclSend");
+        if (bytes && first == ncclSuccess) note(R->Recv(frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream), "ncclRecv");
     }
-    RCCL_TRY(R, R->GroupEnd());
+    note(R->GroupEnd(), "ncclGroupEnd");
+    if (first != ncclSuccess) return fail(MIRHI_ERR_DEVICE, "Vulkan error: RCCL: %s (%s)", R->GetErrorString(first), what);
     HIP_TRY(hipEventRecord(comm->done, stream));             // ... and whatever follows on the lane starts behind the exchange
     HIP_TRY(hipStreamWaitEvent(lane, comm->done, 0));
     return MIRHI_OK;

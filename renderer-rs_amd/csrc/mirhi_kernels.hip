@@ -45,7 +45,7 @@ hipError_t upload_srgb_lut(const float* lut, hipStream_t stream) {
 // A plain launch, or -- when the caller wants the dispatch timed -- one with an event pair attached to the dispatch itself.
 #define MIRHI_LAUNCH(kernel, grid, block, stream, t, ...)                                                               \
     do {                                                                                                                \
-        if ((t).start) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \
+        if ((t).start || (t).stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                           \
     } while (0)
 
@@ -146,20 +146,21 @@ hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* c
 }
 
 template <int KEYED, int TP, int TEAMS = 1>
-static void launch_raster_batch_k(const RasterBatch& B, uint32_t programs, dim3 grid, hipStream_t stream) {
+static void launch_raster_batch_k(const RasterBatch& B, uint32_t programs, dim3 grid, hipStream_t stream, LaunchTiming t) {
     const dim3 block(RASTER_THREADS * TEAMS);
     if (TEAMS > 1) {
-        if (programs == 2) hipLaunchKernelGGL((raster_kernel_batch<2, KEYED, TP, TEAMS>), grid, block, 0, stream, B);
-        else hipLaunchKernelGGL((raster_kernel_batch<4, KEYED, TP, TEAMS>), grid, block, 0, stream, B);
+        if (programs == 2) MIRHI_LAUNCH((raster_kernel_batch<2, KEYED, TP, TEAMS>), grid, block, stream, t, B);
+        else MIRHI_LAUNCH((raster_kernel_batch<4, KEYED, TP, TEAMS>), grid, block, stream, t, B);
         return;
     }
-    if (programs == 2) hipLaunchKernelGGL((raster_kernel_batch<2, KEYED, TP>), grid, block, 0, stream, B);
-    else if (programs == 3) hipLaunchKernelGGL((raster_kernel_batch<3, KEYED, TP>), grid, block, 0, stream, B);
-    else if (programs >= 4) hipLaunchKernelGGL((raster_kernel_batch<4, KEYED, TP>), grid, block, 0, stream, B);
-    else hipLaunchKernelGGL((raster_kernel_batch<1, KEYED, TP>), grid, block, 0, stream, B);
+    if (programs == 2) MIRHI_LAUNCH((raster_kernel_batch<2, KEYED, TP>), grid, block, stream, t, B);
+    else if (programs == 3) MIRHI_LAUNCH((raster_kernel_batch<3, KEYED, TP>), grid, block, stream, t, B);
+    else if (programs >= 4) MIRHI_LAUNCH((raster_kernel_batch<4, KEYED, TP>), grid, block, stream, t, B);
+    else MIRHI_LAUNCH((raster_kernel_batch<1, KEYED, TP>), grid, block, stream, t, B);
 }
 
-hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream) {
+hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream, hipEvent_t stop) {
+    LaunchTiming t{}; t.stop = stop;
     const PassParams& P = *Ps[0];
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
@@ -173,9 +174,9 @@ hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* co
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     // only the variants a frame loop meets are instantiated in batched form: LESS / LESS_OR_EQUAL keys, with and without the
     // triangle-parallel path and the two-team mesh mode; everything else goes scope by scope (mirhi_queue_submit checks)
-    if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) launch_raster_batch_k<0, 1, 2>(B, programs, grid, stream);
-    else if (P.tp_max_area) launch_raster_batch_k<0, 1>(B, programs, grid, stream);
-    else launch_raster_batch_k<0, 0>(B, programs, grid, stream);
+    if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) launch_raster_batch_k<0, 1, 2>(B, programs, grid, stream, t);
+    else if (P.tp_max_area) launch_raster_batch_k<0, 1>(B, programs, grid, stream, t);
+    else launch_raster_batch_k<0, 0>(B, programs, grid, stream, t);
     (void)plain;
     return hipGetLastError();
 }

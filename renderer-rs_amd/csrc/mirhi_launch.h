@@ -8,7 +8,8 @@ namespace mirhi {
 // P: host copy (launch geometry); dev_params: the same parameters in device memory, read by the kernels.
 // Timing: a non-null event pair is attached to the dispatch itself (hipExtLaunchKernelGGL): hipEventElapsedTime(start, stop)
 // is then the kernel's own begin -> end on the GPU clock, what rocprofv3 --kernel-trace reports, with no event-record
-// commands of its own in the stream.  Null events: a plain launch.
+// commands of its own in the stream.  Null events: a plain launch.  A stop event alone: the dispatch's completion signal, which is
+// how a submit's fence is signalled (mirhi_queue_submit).
 struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; };
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
@@ -21,7 +22,8 @@ bool raster_batchable(const PassParams& P);                                 // a
 uint64_t raster_variant_key(const PassParams& P, uint32_t programs);        // equal keys <=> the same raster_kernel instantiation and grid
 hipError_t launch_vertex_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream);
 hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream);
-hipError_t launch_raster_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream);
+hipError_t launch_raster_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t* const* big_count, uint32_t n, uint32_t programs, hipStream_t stream,
+                               hipEvent_t stop = nullptr);      // stop: signalled by the dispatch's completion (a submit's fence)
 // profiling only: counts the fragments the scope's binned triangles cover (before any depth test) into P.frag_stats[1];
 // runs between the geometry and the raster kernel (the raster kernel re-arms the bin counters)
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t = {});

@@ -201,12 +201,15 @@ public:
         check(mirhi_device_create(ordinal, &h));
         return std::shared_ptr<Device>(new Device(h));
     }
-    ~Device() { if (h_) mirhi_device_destroy(h_); }
+    // a device some other owner created and will destroy (the frame loop of include/mirhost.h runs on its caller's device)
+    static std::shared_ptr<Device> borrow(mirhi_device* h) { auto d = std::shared_ptr<Device>(new Device(h)); d->owned_ = false; return d; }
+    ~Device() { if (h_ && owned_) mirhi_device_destroy(h_); }
     mirhi_device* handle() const { return h_; }
     void wait_idle() const { check(mirhi_device_wait_idle(h_)); }   // device.rs:290-293
 private:
     explicit Device(mirhi_device* h) : h_(h) {}
     mirhi_device* h_;
+    bool owned_ = true;
 };
 
 enum class BufferUsage { Vertex = 0, Index, Uniform, Storage, Staging, Indirect };   // buffer.rs:47-60
@@ -609,8 +612,10 @@ struct FrameData {
 
 class FrameManager {
 public:
-    FrameManager(std::shared_ptr<Device> device, const CommandPool& pool) : device_(device) {
-        for (size_t i = 0; i < MAX_FRAMES_IN_FLIGHT; i++) frames_.emplace_back(device, pool);
+    // frames_in_flight: the reference's constant (lib.rs:43) unless a measurement asks for another depth
+    FrameManager(std::shared_ptr<Device> device, const CommandPool& pool, size_t frames_in_flight = MAX_FRAMES_IN_FLIGHT) : device_(device) {
+        frames_.reserve(frames_in_flight ? frames_in_flight : 1);
+        for (size_t i = 0; i < (frames_in_flight ? frames_in_flight : 1); i++) frames_.emplace_back(device, pool);
     }
     void wait_for_frame() const { frames_[current_].in_flight_fence.wait(UINT64_MAX); }             // :299-304
     bool acquire_next_image(uint32_t image_count) { image_index_ = (image_index_ + 1) % image_count; return false; }   // :341-355
@@ -624,7 +629,7 @@ public:
         check(mirhi_queue_submit(device_->handle(), 1, cmds, frames_[current_].in_flight_fence.handle()));
     }
     bool present() const { return false; }                                                           // :499-518 (offscreen: nothing to present)
-    void next_frame() { current_ = (current_ + 1) % MAX_FRAMES_IN_FLIGHT; }                          // :537-539
+    void next_frame() { current_ = (current_ + 1) % frames_.size(); }                                // :537-539
     void wait_for_all_frames() const { for (auto& f : frames_) if (!f.in_flight_fence.is_signaled()) f.in_flight_fence.wait(UINT64_MAX); }
     const FrameData& current_frame() const { return frames_[current_]; }
     size_t current_frame_index() const { return current_; }
