@@ -59,6 +59,11 @@ def parse_args():
     ap.add_argument("--frames-per-submit", type=int, default=1,
                     help="command buffers handed to one mirhi_queue_submit call (vkQueueSubmit with several command buffers): frames of "
                          "equal shape then share one batch of kernel launches; frames in flight = this x --frames-in-flight")
+    ap.add_argument("--record-each-frame", action="store_true",
+                    help="the timed region itself is the reference-shaped loop: every frame waits on its in-flight fence, resets and RE-RECORDS "
+                         "its command buffer, ends and submits it with the fence (renderer.rs:367-449,452-557), natively through libmirhost.so. "
+                         "Without the flag that loop is measured beside the headline (rerecorded_submit)")
+    ap.add_argument("--other-workloads", default="c3,c4,c5", help="N = 1: short passes of these workloads after the headline (workloads{} in the line); '' = none")
     ap.add_argument("--profile-pass-only", action="store_true",
                     help="skip the timed region: only the per-dispatch timing passes (the command profiled with rocprofv3 --pmc)")
     ap.add_argument("--timeline-out", default=None, help="write the per-dispatch timeline of the in-flight pass to this JSON file")
@@ -227,9 +232,12 @@ def main():
     class Rig:
         """A device with `lanes` frames in flight: one colour target + command buffer per frame (swapchain images)."""
 
-        def __init__(self, lanes, band=None, rows=None, per_submit=1):
-            self.dev = m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-            self.dev.set_queue_lanes(lanes)
+        def __init__(self, lanes, band=None, rows=None, per_submit=1, dev=None, scene=scene):
+            self.owns_dev = dev is None
+            self.dev = dev or m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+            self.scene = scene
+            if self.owns_dev:
+                self.dev.set_queue_lanes(lanes)
             if band is not None:
                 self.dev.set_tile_split(*band)
             wrap = make_wrap()
@@ -241,6 +249,16 @@ def main():
                 self.slots.append(m.SceneResources(self.dev, scene, fmt, color_image=target, wrap_buffers=wrap))
                 self.slots[-1].cmd.set_queue_lane((i // per_submit) % lanes)      # group g = slots [g * per_submit, ...) on lane g
             self.groups = [self.slots[g * per_submit:(g + 1) * per_submit] for g in range(lanes)]
+
+        def swapchain(self, count):
+            """`count` more colour targets of this rig's scene: the swapchain images of the reference-shaped loop"""
+            out = []
+            for _ in range(count):
+                frame = torch.zeros((self.scene.height, self.scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
+                self.frames.append(frame)
+                out.append(m.Image(self.dev, self.scene.width, self.scene.height, fmt, device_ptr=frame.data_ptr()))
+            self.extra_images = getattr(self, "extra_images", []) + out
+            return out
 
         def next_slot(self):
             i = self.counter % len(self.slots)
@@ -255,10 +273,10 @@ def main():
             for g in range(lanes):
                 grp = []
                 for _ in range(per_submit):
-                    frame = torch.zeros((scene.height, scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
-                    target = m.Image(self.dev, scene.width, scene.height, fmt, device_ptr=frame.data_ptr())
+                    frame = torch.zeros((self.scene.height, self.scene.width, 4), dtype=torch.uint8 if bpp == 4 else torch.float32, device="cuda")
+                    target = m.Image(self.dev, self.scene.width, self.scene.height, fmt, device_ptr=frame.data_ptr())
                     self.frames.append(frame)
-                    sl = m.SceneResources(self.dev, scene, fmt, color_image=target, wrap_buffers=wrap)
+                    sl = m.SceneResources(self.dev, self.scene, fmt, color_image=target, wrap_buffers=wrap)
                     sl.cmd.set_queue_lane(g)
                     self.slots.append(sl)
                     grp.append(sl)
@@ -280,7 +298,10 @@ def main():
             for sl in self.slots:                     # shared buffers are destroyed once
                 sl.objs = [o for o in sl.objs if not (id(o) in seen or seen.add(id(o)))]
                 sl.destroy()
-            self.dev.destroy()
+            for im in getattr(self, "extra_images", []):
+                im.destroy()
+            if self.owns_dev:
+                self.dev.destroy()
 
     nfif = max(1, min(8, args.frames_in_flight))
     per_submit = max(1, min(8, args.frames_per_submit))
@@ -332,7 +353,18 @@ def main():
                 else:
                     multigpu.all_gather_bands(rig.frames[rig.slots.index(sl)], rank, world, via_host=(args.backend == "gloo"))
 
+    floop = None
+    if args.record_each_frame:
+        if split or world > 1 or per_submit != 1:
+            raise SystemExit("bench.py: --record-each-frame measures the one-GPU frame loop (no split, one frame per submit)")
+        from renderer_rs_amd import frameloop
+        # Renderer::render_frame natively: nfif frames in flight, nfif + 1 swapchain images (swapchain.rs:228-236), every frame re-recorded
+        floop = frameloop.FrameLoop(dev, rig.slots[0], rig.swapchain(nfif + 1), frames_in_flight=nfif)
+
     def step():
+        if floop is not None:
+            floop.run(fps)
+            return
         for _ in range(fps // per_submit):
             frames()
 
@@ -427,6 +459,106 @@ def main():
                                         "frames": nb * 8, "us_per_frame": round(1e6 * d1 / (nb * 8), 4)}
         except Exception as e:
             extras["batched_submit"] = {"error": repr(e)}
+    def rerecorded(rig_, fif, frames_, vary=0, phases=False):
+        """the reference-shaped loop (wait fence -> reset -> re-record -> end -> submit with fence) on `rig_`'s device, natively"""
+        from renderer_rs_amd import frameloop
+        loop = frameloop.FrameLoop(rig_.dev, rig_.slots[0], rig_.swapchain(fif + 1), frames_in_flight=fif, vary_triangles=vary)
+        try:
+            loop.run(max(32, frames_ // 4))
+            sec = min(loop.run(frames_) for _ in range(2))
+            out_ = {"value": round(rig_.scene.num_triangles * frames_ / sec / 1e6, 3), "unit": "Mtris/s", "us_per_frame": round(1e6 * sec / frames_, 4),
+                    "frames_in_flight": fif, "frames": frames_}
+            if phases:
+                loop.phase_seconds(True)
+                loop.run(frames_)
+                ph = loop.phase_seconds(False)
+                out_["host_us_per_frame"] = {k: round(1e6 * v / frames_, 3) for k, v in zip(("fence_wait", "record", "end", "submit"), ph)}
+            return out_
+        finally:
+            loop.destroy()
+
+    def resubmitted(rig_, slots_, frames_):
+        for i in range(max(16, frames_ // 8)):
+            slots_[i % len(slots_)].render()
+        rig_.dev.wait_idle()
+        t1 = time.perf_counter()
+        for i in range(frames_):
+            slots_[i % len(slots_)].render()
+        rig_.dev.wait_idle()
+        d1 = time.perf_counter() - t1
+        return {"value": round(rig_.scene.num_triangles * frames_ / d1 / 1e6, 3), "unit": "Mtris/s", "us_per_frame": round(1e6 * d1 / frames_, 4),
+                "frames_in_flight": len(slots_), "frames": frames_}
+
+    if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
+        try:
+            if floop is not None:
+                floop.destroy()
+                floop = None
+            n_re = max(512, 4 * fps)
+            # the reference's frame loop on the headline's device and queue lanes: every frame re-recorded and fenced (renderer.rs:367-557)
+            extras["rerecorded_submit"] = rerecorded(rig, nfif, n_re, phases=True)
+            # ... and with a triangle count that changes from frame to frame (another launch plan every frame)
+            extras["rerecorded_submit"]["changing_triangle_count"] = rerecorded(rig, nfif, n_re, vary=7)
+        except Exception as e:
+            extras["rerecorded_submit"] = {"error": repr(e)}
+        try:
+            # the reference's MAX_FRAMES_IN_FLIGHT = 2 (crates/renderer/src/lib.rs:43): two queue lanes, two command buffers
+            dev.wait_idle()
+            dev.set_queue_lanes(2)
+            two = rig.slots[:2]
+            for i, sl in enumerate(two):
+                sl.cmd.set_queue_lane(i)
+            n2 = max(512, 2 * fps)
+            extras["frames_in_flight_2"] = {"resubmitted": resubmitted(rig, two, n2), "rerecorded": rerecorded(rig, 2, n2, phases=True)}
+            dev.wait_idle()
+            dev.set_queue_lanes(nfif)
+            for i, sl in enumerate(rig.slots[:nfif]):
+                sl.cmd.set_queue_lane(i % nfif)
+        except Exception as e:
+            extras["frames_in_flight_2"] = {"error": repr(e)}
+    if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only and args.other_workloads:
+        # The other single-GPU BASELINE workloads, one short pass each on the same device and queue lanes (the headline fields above stay
+        # the C2 figures): frame loop of pre-recorded command buffers with `nfif` frames in flight, the reference-shaped re-recorded loop,
+        # and the isolated kernel durations behind their own roofline.
+        wl_out = {}
+        for other in [w_ for w_ in args.other_workloads.split(",") if w_ and w_ in WORKLOADS and w_ != wname]:
+            try:
+                odesc, omake, _ofps = WORKLOADS[other]
+                osc = omake(m.scenes)
+                orig = Rig(nfif, dev=dev, scene=osc)
+                t1 = time.perf_counter()
+                nwarm = 0
+                while time.perf_counter() - t1 < 0.15:
+                    orig.slots[nwarm % nfif].render()
+                    nwarm += 1
+                dev.wait_idle()
+                us_guess = 1e6 * (time.perf_counter() - t1) / max(1, nwarm)
+                nfr = int(max(64, min(4096, 0.3e6 / max(1.0, us_guess))))
+                res_o = resubmitted(orig, orig.slots, nfr)
+                rer_o = rerecorded(orig, nfif, nfr)
+                dev.wait_idle(); dev.reset_kernel_times(); dev.set_profiling(m.Profile.TIMING)
+                for _ in range(32):
+                    orig.slots[0].render()
+                dev.wait_idle()
+                kt = {name: dev.kernel_time(k) for k, name in enumerate(m.Kernel.NAMES)}
+                dev.set_profiling(0); dev.reset_kernel_times()
+                k_us = {name: (1e3 * ms / n_ if n_ else 0.0) for name, (ms, n_) in kt.items()}
+                oalg = osc.algorithmic_bytes(bpp_out=bpp)
+                otraffic, onote = measured_traffic(other, mbuild.source_hash())
+                ach = oalg / (k_us["raster"] * 1e-6) / 1e9 if k_us["raster"] > 0 else 0.0
+                fus = k_us["raster"] + k_us["geometry"] + k_us["vertex"]
+                wl_out[other] = {"workload": f"{other}: {odesc}", "triangles": osc.num_triangles, "width": osc.width, "height": osc.height,
+                                 "value": res_o["value"], "unit": "Mtris/s", "us_per_frame": res_o["us_per_frame"], "frames": nfr, "frames_in_flight": nfif,
+                                 "rerecorded_submit": {"value": rer_o["value"], "us_per_frame": rer_o["us_per_frame"]},
+                                 "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": otraffic["frame_hbm_bytes"] if otraffic else None,
+                                              "traffic_source": onote, "algorithmic_bytes_per_launch": oalg, "avg_kernel_us": round(k_us["raster"], 3),
+                                              "geometry_kernel_us": round(k_us["geometry"], 3), "vertex_kernel_us": round(k_us["vertex"], 3),
+                                              "frame_frac": round(oalg / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if fus > 0 else None}}
+                orig.destroy()
+            except Exception as e:
+                wl_out[other] = {"error": repr(e)}
+        extras["workloads"] = wl_out
     if world > 1 and split and not args.no_extras and not args.profile_pass_only:
         try:
             # the same workload, whole frame on ONE GPU (every rank renders its own unsplit copy, no exchange): the N = 1 point of the
@@ -448,6 +580,8 @@ def main():
                                                "note": "whole frame per GPU, no split, no exchange (all ranks at once, slowest rank)"}
         except Exception as e:          # never let a secondary measurement take the primary line down
             extras["one_gpu_same_workload"] = {"error": repr(e)}
+    if floop is not None:
+        floop.destroy()
     rig.destroy(comm)        # (frees its queue lanes: a second device beside it would share the 4 hardware queues with it)
 
     if rank == 0:
@@ -478,7 +612,9 @@ def main():
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
                        "parallelism": (f"tile-row split x{world} + band exchange ({'RCCL through the C ABI, ' + args.gather_algo if comm is not None else 'torch.distributed ' + args.backend})" if split
                                        else (f"afr{world}" if world > 1 else "single")),
-                       "frames_per_step": fps, "prewarm_seconds": args.prewarm_seconds, "frames_in_flight": nfif * per_submit, "queue_lanes": nfif, "frames_per_submit": per_submit},
+                       "frames_per_step": fps, "prewarm_seconds": args.prewarm_seconds, "frames_in_flight": nfif * per_submit, "queue_lanes": nfif, "frames_per_submit": per_submit,
+                       "command_buffers": "re-recorded every frame (wait fence, reset, record, end, submit with fence: renderer.rs:367-557), native loop"
+                                          if args.record_each_frame else "recorded once, resubmitted"},
             "timed_region_s": round(dt, 6), "us_per_frame": round(1e6 * dt / max(1, args.steps * fps), 4),
             "shaded_mpix_per_s": round(shaded_per_frame * frames_total / dt / 1e6, 1),
             "overdraw": round(covered / shaded, 4) if shaded else None,

@@ -51,6 +51,9 @@ mirhi_result mirhost_frame_loop_create(mirhi_device* dev, const mirhost_frame_de
 mirhi_result mirhost_frame_loop_run(mirhost_frame_loop* loop, uint64_t frames, double* seconds);
 /* index into desc.images of the frame rendered last, and how many frames this loop has rendered */
 mirhi_result mirhost_frame_loop_last_image(const mirhost_frame_loop* loop, uint32_t* image_index, uint64_t* frames_rendered);
+/* host seconds per phase since the last call -- [0] fence wait, [1] recording (reset .. end_rendering), [2] end(), [3] submit -- and
+ * switches the accounting on / off (four clock reads per frame while it is on) */
+mirhi_result mirhost_frame_loop_phase_seconds(mirhost_frame_loop* loop, int32_t enable, double* out4 /* may be NULL */);
 mirhi_result mirhost_frame_loop_destroy(mirhost_frame_loop* loop);
 const char*  mirhost_last_error_message(void);
 

@@ -104,6 +104,8 @@ struct mirhi_device {
     std::vector<mirhi_fence*> fences;         // live fences (guarded by mu): a command buffer that is destroyed or re-recorded
                                               //   while a fence still lists it hands its device status over first
     std::vector<mirhi_cmd*> cmds;             // live command buffers (guarded by mu): lanes that go away are forgotten by all of them
+    std::vector<mirhi_image*> images;         // live images (guarded by mu): a recording may outlive an attachment it names
+    hipEvent_t order_event = nullptr;         // cross-lane attachment ordering (mirhi_image::last_stream)
     mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
     std::string deferred_msg;
     double total_ms[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
@@ -130,6 +132,11 @@ struct mirhi_image {
     bool owned;
     uint32_t levels = 1;      // mip levels stored contiguously behind level 0 (mirhi_image_generate_mips)
     uint32_t max_anisotropy = 1;   // sampler state (mirhi_image_set_max_anisotropy): 1 = trilinear
+    // Attachment ordering across queue lanes: the reference submits everything to one queue, so a scope that LOADs (or overwrites)
+    // what an earlier submission rendered is behind it by construction; here two command buffers may sit on different lanes.  The
+    // stream, command buffer and submission that used this image as an attachment last: a submit on ANOTHER stream waits for it
+    // (one event record + stream wait), unless a fence / wait_idle has reported that submission finished -- the frame loop's case.
+    hipStream_t last_stream = nullptr; const mirhi_cmd* last_cmd = nullptr; uint64_t last_seq = 0;
 };
 
 struct mirhi_pipeline {
@@ -362,6 +369,7 @@ extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
     if (dev->base_stop) (void)hipEventDestroy(dev->base_stop);
     for (auto& e : dev->free_events) (void)hipEventDestroy(e);
     if (dev->frag_stats) (void)hipFree(dev->frag_stats);
+    if (dev->order_event) (void)hipEventDestroy(dev->order_event);
     if (dev->owns_stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return MIRHI_OK;
@@ -510,6 +518,7 @@ static mirhi_result image_common(mirhi_device* dev, uint32_t w, uint32_t h, mirh
     }
     mirhi_image* img = new (std::nothrow) mirhi_image{dev, w, h, f, (uint8_t*)p, ext == nullptr};
     if (!img) { if (!ext) (void)hipFree(p); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed"); }
+    { std::lock_guard<std::mutex> lock(dev->mu); dev->images.push_back(img); }
     dev->children++;
     *out = img;
     return MIRHI_OK;
@@ -601,6 +610,7 @@ extern "C" mirhi_result mirhi_image_destroy(mirhi_image* img) {
     NULL_CHECK(img, "image");
     (void)hipSetDevice(img->dev->ordinal);
     if (img->owned) { (void)sync_all_lanes(img->dev); (void)hipFree(img->ptr); }
+    { std::lock_guard<std::mutex> lock(img->dev->mu); auto& v = img->dev->images; v.erase(std::remove(v.begin(), v.end(), img), v.end()); }
     img->dev->children--;
     delete img;
     return MIRHI_OK;
@@ -1381,6 +1391,18 @@ static mirhi_result build_plan(mirhi_cmd* cmd) {
     w.grow_pool = false; w.replan = false;
     w.status_host[0] = 0; w.status_host[1] = 0; w.status_host[2] = 0;
     w.big_counts = w.counters + CTR_BIG;
+    if (!w.dirty && getenv("MIRHI_VERIFY_IDLE")) {
+        // Test hook: what the plan relies on instead of clearing -- every kernel leaves the workspace re-armed -- is checked here, on the
+        // host: all bin and pool counters zero, the big-list counter of the next parity zero, every page-table entry PAGE_EMPTY.
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<uint32_t> c(w.counters_words), t(w.bin_table_bytes / 4);
+        HIP_TRY(hipMemcpy(c.data(), w.counters, c.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(t.data(), w.bin_table, t.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad_c = 0, bad_t = 0;
+        for (size_t i = 0; i < c.size(); i++) bad_c += (c[i] != 0u && i != (size_t)(CTR_BIG + (w.parity ^ 1u))) ? 1 : 0;
+        for (uint32_t v : t) bad_t += v != PAGE_EMPTY ? 1 : 0;
+        if (bad_c || bad_t) return fail(MIRHI_ERR_DEVICE, "Vulkan error: workspace not idle between frames: %zu counter words, %zu page-table entries left set", bad_c, bad_t);
+    }
     if (w.dirty) {
         HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
         HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, stream));
@@ -1611,6 +1633,36 @@ static mirhi_result timing_begin(mirhi_device* dev, uint32_t kernel, uint32_t la
     return MIRHI_OK;
 }
 
+// Attachments of a command buffer's recording that are still live images (dev->mu held).
+template <typename F>
+static void for_each_attachment(mirhi_device* dev, const mirhi_cmd* c, F&& f) {
+    for (const RecordedPass& pass : c->planned)
+        for (mirhi_image* img : {pass.info.color_image, pass.info.depth_image, pass.info.prim_id_image})
+            if (img && std::find(dev->images.begin(), dev->images.end(), img) != dev->images.end()) f(img);
+}
+// `c` is about to run on `stream`: anything that used one of its attachments last on another stream, and is not known to have finished, goes first.
+static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream_t stream) {
+    hipError_t err = hipSuccess;
+    for_each_attachment(dev, c, [&](mirhi_image* img) {
+        if (img->last_stream && img->last_stream != stream && err == hipSuccess) {
+            bool live = false;
+            for (hipStream_t st : dev->lanes) live |= st == img->last_stream;
+            if (live) {
+                if (!dev->order_event) err = hipEventCreateWithFlags(&dev->order_event, hipEventDisableTiming);
+                if (err == hipSuccess) err = hipEventRecord(dev->order_event, img->last_stream);
+                if (err == hipSuccess) err = hipStreamWaitEvent(stream, dev->order_event, 0);
+            }
+        }
+        img->last_stream = stream; img->last_cmd = c; img->last_seq = c->submit_seq;
+    });
+    if (err != hipSuccess) return hip_fail(err, "attachment ordering across queue lanes");
+    return MIRHI_OK;
+}
+// submission `seq` of `c` has finished: its attachments need no ordering any more (unless something newer used them since)
+static void release_attachments(mirhi_device* dev, const mirhi_cmd* c, uint64_t seq) {
+    for_each_attachment(dev, c, [&](mirhi_image* img) { if (img->last_cmd == c && img->last_seq == seq) { img->last_stream = nullptr; img->last_cmd = nullptr; } });
+}
+
 extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence) {
     NULL_CHECK(dev, "device");
     if (cmd_count) NULL_CHECK(cmds, "cmds");
@@ -1667,6 +1719,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             mirhi_cmd* c = cmds[i];
             if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
             c->last_stream = stream; c->pending = true; c->submit_seq++;
+            { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
             if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
             P[i] = &c->plan[0];
             dp[i] = c->ws.params + c->ws.parity;
@@ -1685,6 +1738,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
         if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
         c->last_stream = stream; c->pending = true; c->submit_seq++;
+        { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
             const PassParams& P = c->plan[pi];
@@ -1796,6 +1850,7 @@ static mirhi_result check_status_words(mirhi_device* dev) {
     for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
     dev->unchecked.clear();
     for (mirhi_cmd* c : dev->cmds) c->pending = false;       // (called with every lane synchronised)
+    for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_cmd = nullptr; }
     if (dev->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = dev->deferred; g_last_error = dev->deferred_msg; } dev->deferred = MIRHI_OK; dev->deferred_msg.clear(); }
     return r;
 }
@@ -1807,6 +1862,7 @@ static mirhi_result fence_complete(mirhi_fence* f) {
         for (size_t i = 0; i < f->cmds.size(); i++) {
             mirhi_cmd* c = f->cmds[i];
             const mirhi_result rc = status_of(f->dev, c); if (rc != MIRHI_OK) r = rc;
+            release_attachments(f->dev, c, f->seqs[i]);
             if (c->submit_seq == f->seqs[i]) {              // (a later submission of the same command buffer is still its own fence's business)
                 c->pending = false;
                 auto& u = f->dev->unchecked;

@@ -62,6 +62,7 @@ def lib():
         L.mirhost_frame_loop_create.restype, L.mirhost_frame_loop_create.argtypes = C.c_int32, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(C.c_void_p)]
         L.mirhost_frame_loop_run.restype, L.mirhost_frame_loop_run.argtypes = C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]
         L.mirhost_frame_loop_last_image.restype, L.mirhost_frame_loop_last_image.argtypes = C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.mirhost_frame_loop_phase_seconds.restype, L.mirhost_frame_loop_phase_seconds.argtypes = C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
         L.mirhost_frame_loop_destroy.restype, L.mirhost_frame_loop_destroy.argtypes = C.c_int32, [C.c_void_p]
         L.mirhost_last_error_message.restype, L.mirhost_last_error_message.argtypes = C.c_char_p, []
         _lib = L
@@ -119,6 +120,12 @@ class FrameLoop:
         sec = C.c_double()
         _check(lib().mirhost_frame_loop_run(self.handle, frames, C.byref(sec)))
         return sec.value
+
+    def phase_seconds(self, enable: bool = True):
+        """host seconds per phase since the last call: (fence wait, recording, end(), submit); switches the accounting on / off"""
+        out = (C.c_double * 4)()
+        _check(lib().mirhost_frame_loop_phase_seconds(self.handle, int(enable), out))
+        return tuple(out)
 
     def last_image(self):
         idx, n = C.c_uint32(), C.c_uint64()

@@ -67,18 +67,29 @@ struct mirhost_frame_loop {
         cmd.end_rendering();                                                // :551
     }
 
+    // host time per phase, accumulated when the caller asked for it (mirhost_frame_loop_phase_seconds): fence wait, recording
+    // (reset .. end_rendering), end() (the launch plan), submit
+    bool timed = false;
+    double phase[4] = {0, 0, 0, 0};
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
     // renderer.rs:367-449
     void render_frame() {
+        const double t0 = timed ? now() : 0.0;
         frames.wait_for_frame();                                            // :371-374  wait_for_fence(in_flight_fences[current_frame])
+        const double t1 = timed ? now() : 0.0;
         frames.acquire_next_image((uint32_t)images.size());                 // :377-390
         frames.begin_frame();                                               // :393-397  reset_fence; :457-467 command_buffer.reset(), begin()
         record_commands(frames.current_frame().command_buffer, frames.image_index());
+        const double t2 = timed ? now() : 0.0;
         frames.end_frame();                                                 // :555 command_buffer.end()
+        const double t3 = timed ? now() : 0.0;
         frames.submit();                                                    // :407-424 queue_submit(..., in_flight_fence)
         frames.present();                                                   // :427-443
         last_image = frames.image_index();
         frames.next_frame();                                                // :446 current_frame = (current_frame + 1) % MAX_FRAMES_IN_FLIGHT
         frame_number++;
+        if (timed) { const double t4 = now(); phase[0] += t1 - t0; phase[1] += t2 - t1; phase[2] += t3 - t2; phase[3] += t4 - t3; }
     }
 };
 
@@ -113,6 +124,14 @@ extern "C" mirhi_result mirhost_frame_loop_last_image(const mirhost_frame_loop* 
     if (!loop) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: loop is null");
     if (image_index) *image_index = loop->last_image;
     if (frames_rendered) *frames_rendered = loop->frame_number;
+    return MIRHI_OK;
+}
+
+extern "C" mirhi_result mirhost_frame_loop_phase_seconds(mirhost_frame_loop* loop, int32_t enable, double* out4) {
+    if (!loop) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: loop is null");
+    if (out4) for (int k = 0; k < 4; k++) out4[k] = loop->phase[k];
+    for (double& p : loop->phase) p = 0.0;
+    loop->timed = enable != 0;
     return MIRHI_OK;
 }
 

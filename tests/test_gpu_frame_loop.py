@@ -1,0 +1,157 @@
+"""GPU tests of the draw-submit loop in the reference's shape (crates/renderer/src/renderer.rs:367-449,452-557,
+frame_manager.rs:299-539): every frame waits on its in-flight fence, resets and RE-RECORDS its command buffer, ends it and
+submits it with the fence.  Round 3 made that path cheap (plan cache, host-written parameter block, no clears, fence on the
+last dispatch); these tests pin that it is still the oracle's frame when the recording changes from frame to frame.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _check
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(res):
+    out = {"color": res.color.read()}
+    if res.prim:
+        out["prim"] = res.prim.read()
+    if res.depth:
+        out["depth"] = res.depth.read()
+    return out
+
+
+def test_rerecorded_frames_with_changing_uniform_and_triangle_count(mirhi, oracle, scenes):
+    """Two frames in flight on two queue lanes, eight frames; every frame re-records its command buffer with another object
+    transform (its slot's uniform buffer rewritten first) AND another triangle count.  Every frame is checked against the
+    oracle's render of exactly that frame: winning primitive ids bit for bit, colour within 1e-4."""
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(2)
+    base = scenes.displaced_sphere(40, 31, 384, 240, seed=11)
+    slots = []
+    for k in range(2):
+        sc = copy.deepcopy(base)
+        res = mirhi.SceneResources(dev, sc, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+        res.cmd.set_queue_lane(k)
+        slots.append((sc, res, mirhi.Fence(dev, signaled=True)))
+    full = base.draws[0].count
+    expected = {}
+
+    def verify(f):
+        sc, res, fence = slots[f % 2]
+        fence.wait()
+        _check(_read(res), expected.pop(f), f"frame {f}")
+
+    for f in range(8):
+        sc, res, fence = slots[f % 2]
+        if f >= 2:
+            verify(f - 2)                                   # wait_for_fence(in_flight_fences[current_frame]) -- and look at that frame
+        fence.reset()
+        d = sc.draws[0]
+        d.count = full - 3 * (37 * f)                        # another triangle count every frame
+        d.object = scenes.object_ubo(scenes.trs((1.0, 1.0 - 0.03 * f, 1.0), scenes.quat_axis_angle((0.0, 1.0, 0.0), 0.35 * f), (0.02 * f, 0.0, 0.0)))
+        res.draw_state[0]["object"].write_data(0, d.object)      # Buffer::write_data: this slot's uniform buffer, its previous frame has been waited for
+        res.cmd.reset()
+        res.record()                                         # begin .. end: a new recording of another shape
+        res.render(fence)
+        expected[f] = oracle.render(sc, want_bgra8=False)
+    verify(6)
+    verify(7)
+    for sc, res, fence in slots:
+        res.destroy()
+        fence.destroy()
+    dev.destroy()
+
+
+@pytest.mark.parametrize("frames_in_flight,lanes", [(2, 2), (2, 1), (3, 4)])
+def test_native_frame_loop_matches_the_oracle(mirhi, oracle, scenes, frames_in_flight, lanes):
+    """libmirhost.so (Renderer::render_frame natively, include/mirhost.h): after n frames the image rendered last is the oracle's
+    frame -- with the triangle count changing every frame (vary_triangles = 5: frame f draws count - 3 * (f % 5) vertices), so the
+    launch plan is rebuilt in every end(), and without (the plan cache path)."""
+    from renderer_rs_amd import frameloop
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(lanes)
+    for make in (lambda: scenes.random_triangles(3000, 640, 360, seed=21), lambda: scenes.displaced_sphere(30, 23, 320, 200, seed=5)):
+        scene = make()
+        res = mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB)
+        images = [mirhi.Image(dev, scene.width, scene.height, mirhi.Format.B8G8R8A8_SRGB) for _ in range(frames_in_flight + 1)]
+        for vary, n in ((0, 7), (5, 9), (5, 13)):
+            loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=frames_in_flight, vary_triangles=vary)
+            loop.run(n)
+            img, rendered = loop.last_image()
+            assert rendered == n
+            sc = copy.deepcopy(scene)
+            if vary:
+                sc.draws[0].count -= 3 * ((n - 1) % vary)
+            ref = oracle.render(sc, want_bgra8=True)
+            got = img.read()
+            d = np.abs(got.astype(np.int32) - ref["bgra8"].astype(np.int32))
+            assert d.max() <= 1, f"{scene.name} vary {vary} frame {n}: sRGB8 differs by {d.max()} LSB"
+            # every swapchain image holds one of the last frames_in_flight + 1 frames
+            loop.destroy()
+        for im in images:
+            im.destroy()
+        res.destroy()
+    dev.destroy()
+
+
+def test_one_command_buffer_through_many_shapes_without_clears(mirhi, oracle, scenes, monkeypatch):
+    """The workspace is no longer cleared when a command buffer is re-recorded: the kernels leave counters and page table re-armed and
+    the plan relies on it.  One command buffer is recorded with scene after scene of different size, density and program (so tile
+    count, bin layout, per-XCD bins and big-list use all change under it); MIRHI_VERIFY_IDLE makes end() check the idle state on the
+    host, and every frame must be the oracle's."""
+    monkeypatch.setenv("MIRHI_VERIFY_IDLE", "1")
+    dev = mirhi.Device(0)
+    shared = mirhi.CommandBuffer(dev)
+    makers = [lambda: scenes.random_triangles(4000, 640, 360, seed=3), lambda: scenes.SMALL_CASES["huge"](), lambda: scenes.displaced_sphere(40, 31, 512, 300, seed=2),
+              lambda: scenes.random_triangles(9000, 320, 200, seed=8, rmin=3, rmax=14), lambda: scenes.SMALL_CASES["near_clip"](), lambda: scenes.SMALL_CASES["multi_draw"](),
+              lambda: scenes.random_triangles(500, 1920, 1080, seed=4), lambda: scenes.SMALL_CASES["pbr"](), lambda: scenes.SMALL_CASES["cull_scissor"](),
+              lambda: scenes.displaced_sphere(24, 17, 256, 160, seed=3), lambda: scenes.random_triangles(4000, 640, 360, seed=3)]
+    for rep in range(2):
+        for make in makers:
+            scene = make()
+            res = mirhi.SceneResources(dev, scene, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+            own = res.cmd
+            res.cmd = shared
+            res.record()
+            for _ in range(2):                              # (twice: the second submit runs on what the first left behind)
+                res.render()
+                dev.wait_idle()
+            _check(_read(res), oracle.render(scene, want_bgra8=False), f"{scene.name} (shared command buffer, pass {rep})")
+            res.cmd = own
+            res.destroy()
+    shared.destroy()
+    dev.destroy()
+
+
+def test_dependent_command_buffers_of_one_submit_are_not_batched(mirhi, oracle, scenes):
+    """mirhi_queue_submit([A, B]) where A clears and draws into a target and B LOADs that target and draws on top: the two
+    must run in order, not as one batched launch -- the result is the oracle's two-draw frame."""
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(2)
+    sa = scenes.random_triangles(1500, 320, 200, seed=31)
+    sb = scenes.random_triangles(1500, 320, 200, seed=32)
+    both = copy.deepcopy(sa)
+    both.draws = [copy.deepcopy(sa.draws[0]), copy.deepcopy(sb.draws[0])]
+    for d in both.draws:
+        d.depth_test = d.depth_write = False                 # (no depth: B simply paints over A, in primitive order)
+    sa.draws[0].depth_test = sa.draws[0].depth_write = False
+    sb.draws[0].depth_test = sb.draws[0].depth_write = False
+    target = mirhi.Image(dev, 320, 200, mirhi.Format.R32G32B32A32_SFLOAT)
+    ra = mirhi.SceneResources(dev, sa, color_image=target)
+    rb = mirhi.SceneResources(dev, sb, color_image=target, color_load_op=mirhi.LoadOp.LOAD)
+    ra.cmd.set_queue_lane(0)
+    rb.cmd.set_queue_lane(1)                                 # another lane: the submit has to order B behind A all the same
+    ra.record(); rb.record()
+    fence = mirhi.Fence(dev)
+    for _ in range(3):
+        dev.submit([ra.cmd, rb.cmd], fence)
+        fence.wait(); fence.reset()
+    got = target.read()
+    ref = oracle.render(both, want_bgra8=False)
+    err = np.abs(got[..., :3] - ref["rgba"][..., :3]).max()
+    assert err < 1e-4, f"LOAD after CLEAR in one submit: max |dRGB| = {err}"
+    rb.color = None                                          # (the target is shared: ra's destroy() takes it down)
+    ra.destroy(); rb.destroy(); fence.destroy()
+    dev.destroy()

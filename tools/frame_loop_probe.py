@@ -25,6 +25,11 @@ def main():
             loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=fif, vary_triangles=vary)
             loop.run(max(64, frames // 8))
             t = [loop.run(frames) for _ in range(3)]
+            loop.phase_seconds(True)
+            loop.run(frames)
+            ph = loop.phase_seconds(False)
+            if vary == 0:
+                print(f"   host us/frame: fence wait {1e6 * ph[0] / frames:.2f}, record {1e6 * ph[1] / frames:.2f}, end {1e6 * ph[2] / frames:.2f}, submit {1e6 * ph[3] / frames:.2f}", flush=True)
             img, n = loop.last_image()
             same = bool(np.array_equal(img.read(), ref)) if vary == 0 else None
             out.append((vary, 1e6 * min(t) / frames, same))
