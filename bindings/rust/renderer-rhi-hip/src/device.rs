@@ -47,6 +47,11 @@ impl Device {
     pub fn set_queue_lanes(&self, lanes: u32) -> RhiResult<()> {
         check(unsafe { mirhi_sys::mirhi_device_set_queue_lanes(self.raw, lanes) })
     }
+    /// vkQueueSubmit semantics: `queue_submit` queues the work and returns, a thread of the device makes the kernel launches
+    /// (renderer.rs:407-424 returns as soon as the driver has the submission).  Off by default.
+    pub fn set_submit_thread(&self, enable: bool) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_device_set_submit_thread(self.raw, enable as u32) })
+    }
     /// Screen-tile-row split across the GPUs of a node: this process rasters band `rank` of `world`.
     pub fn set_tile_split(&self, rank: u32, world: u32) -> RhiResult<()> {
         check(unsafe { mirhi_sys::mirhi_device_set_tile_split(self.raw, rank, world) })

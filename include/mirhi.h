@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MIRHI_ABI_VERSION 3u     /* 3: mirhi_pipeline_desc.fragment_discard_enable */
+#define MIRHI_ABI_VERSION 4u     /* 3: mirhi_pipeline_desc.fragment_discard_enable; 4: mirhi_device_set_submit_thread */
 
 /* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
 typedef int32_t mirhi_result;
@@ -74,6 +74,13 @@ mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint3
  * the reference's per-frame command buffers do between their semaphores.  Default 1 = strict submission order.  Set before
  * creating command buffers.  Work submitted on different lanes is unordered unless a fence is waited. */
 mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t lanes);
+/* Submit thread (default off).  vkQueueSubmit hands its work to the driver and returns (renderer.rs:407-424); with the thread on,
+ * mirhi_queue_submit validates the submission, queues it and returns, and a thread of the device makes the kernel launches (HIP takes
+ * 2.3 - 3 us of host time per launch whatever the entry point: 5 - 7 us per frame the render thread can spend recording the next
+ * frame instead).  Everything else keeps its meaning: a fence waits for its submission, wait_idle and every call that reads or writes
+ * a resource first wait until all queued submissions have been issued; an error the launches raise is reported by the submission's
+ * fence (or by wait_idle if it has none).  Submissions are issued in the order they were made. */
+mirhi_result mirhi_device_set_submit_thread(mirhi_device* dev, uint32_t enable);
 /* first/last+1 pixel row of the band rendered by this device for a target of `height` rows */
 mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end);
 

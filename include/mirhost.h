@@ -43,6 +43,7 @@ typedef struct {
     /* frame f draws `count - 3 * (f % vary_triangles)` vertices / indices of draw 0 (0 or 1: every frame the same): a frame loop whose
      * triangle count changes from frame to frame -- the re-recorded command buffer then has another shape every time */
     uint32_t vary_triangles;
+    uint32_t submit_thread;               /* 1: mirhi_device_set_submit_thread(dev, 1) while the loop exists (the device's previous setting is restored at destroy) */
 } mirhost_frame_desc;
 
 typedef struct mirhost_frame_loop mirhost_frame_loop;

@@ -102,7 +102,7 @@ class GatherAlgo:
     DIRECT, BROADCAST = range(2)
 
 
-ABI_VERSION = 3                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
+ABI_VERSION = 4                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
 COMM_ID_BYTES = 128
 
 
@@ -177,6 +177,7 @@ _SIGNATURES = {
     "mirhi_device_name": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32]),
     "mirhi_device_set_tile_split": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "mirhi_device_set_queue_lanes": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "mirhi_device_set_submit_thread": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_band_rows": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mirhi_buffer_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mirhi_buffer_create_with_data": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -310,6 +311,10 @@ class Device:
 
     def set_queue_lanes(self, lanes: int):
         check(lib().mirhi_device_set_queue_lanes(self.handle, lanes))
+
+    def set_submit_thread(self, enable: bool = True):
+        """vkQueueSubmit semantics: submit() queues the work and returns, a thread of the device makes the launches (include/mirhi.h)"""
+        check(lib().mirhi_device_set_submit_thread(self.handle, int(enable)))
 
     def band_rows(self, height: int):
         a, b = C.c_uint32(), C.c_uint32()

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -114,6 +115,18 @@ struct mirhi_device {
     uint64_t frag_scopes = 0;                 // scopes counted into frag_stats since the last reset
     mirhi_device_stats stats{};
     char name[256] = {0};
+    // Submit thread (mirhi_device_set_submit_thread): vkQueueSubmit hands the work to the driver and returns; with the thread on,
+    // mirhi_queue_submit validates, queues the job and returns, and this thread makes the HIP launches (2.3 - 3 us each whatever the
+    // entry point, tools/microbench/launch_paths.hip: 5 - 7 us per frame that the render thread then spends recording the next frame).
+    // Single producer / single consumer ring; the consumer spins while a frame loop feeds it and sleeps after 100 us without work.
+    struct SubmitJob { uint32_t n; mirhi_cmd* cmds[MAX_BATCH > 16 ? MAX_BATCH : 16]; mirhi_fence* fence; };
+    static constexpr uint64_t SQ_SLOTS = 64;
+    std::thread sq_thread;
+    bool sq_on = false;
+    SubmitJob sq_ring[SQ_SLOTS];
+    std::atomic<uint64_t> sq_pushed{0}, sq_done{0};
+    std::atomic<bool> sq_stop{false}, sq_sleeping{false};
+    std::mutex sq_mu; std::condition_variable sq_cv;
 };
 
 struct mirhi_buffer {
@@ -221,6 +234,7 @@ struct mirhi_cmd {
                                            //   re-recording a pending command buffer; this build synchronises instead -- the slow path a frame
                                            //   loop that waits on its fences never takes
     uint64_t submit_seq = 0;               // submissions so far (a fence remembers which one it saw)
+    std::atomic<int> queued{0};            // submissions handed to the submit thread and not yet issued by it
     bool one_time = true;
     bool in_rendering = false;
     std::vector<RecordedPass> passes;
@@ -252,6 +266,7 @@ struct mirhi_fence {
     hipEvent_t join = nullptr;   // cross-lane join for multi-command submits
     bool signaled = false;      // host-visible signaled state
     bool pending = false;       // an event record is outstanding
+    std::atomic<bool> issued{true};   // false while its submission waits in the submit thread's queue (the event is recorded when it is issued)
     std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
     std::vector<uint64_t> seqs;    //   and which submission of each it was (mirhi_cmd::submit_seq)
     mirhi_result deferred = MIRHI_OK;   // status handed over by a listed command buffer that was destroyed / re-recorded since
@@ -324,17 +339,27 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
         if (le != hipSuccess) { if (d->owns_stream) (void)hipStreamDestroy(d->stream); delete d; return hip_fail(le, "sRGB table upload"); }
     }
     *out = d;
+    if (getenv("MIRHI_SUBMIT_THREAD") && atoi(getenv("MIRHI_SUBMIT_THREAD")) != 0) (void)mirhi_device_set_submit_thread(d, 1);   // (test runs: every device with the thread on)
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_create(int32_t ordinal, mirhi_device** out) { return device_create_common(ordinal, nullptr, false, out); }
 extern "C" mirhi_result mirhi_device_create_on_stream(int32_t ordinal, void* stream, mirhi_device** out) { return device_create_common(ordinal, stream, true, out); }
 
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+// every job handed to the submit thread has been issued to the GPU's queues (not: has finished)
+static void drain_submits(mirhi_device* dev) {
+    if (!dev->sq_on) return;
+    const uint64_t want = dev->sq_pushed.load(std::memory_order_acquire);
+    while (dev->sq_done.load(std::memory_order_acquire) < want) cpu_relax();
+}
 static mirhi_result sync_all_lanes(mirhi_device* dev) {
+    drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
     for (hipStream_t st : dev->lanes) HIP_TRY(hipStreamSynchronize(st));
     return MIRHI_OK;
 }
 static mirhi_result check_status_words(mirhi_device* dev);
+extern "C" mirhi_result mirhi_device_set_submit_thread(mirhi_device* dev, uint32_t enable);
 extern "C" mirhi_result mirhi_device_wait_idle(mirhi_device* dev) {
     NULL_CHECK(dev, "device");
     mirhi_result r = sync_all_lanes(dev);
@@ -363,6 +388,7 @@ extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
     NULL_CHECK(dev, "device");
     if (dev->children.load() != 0)
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: device still has %d live child objects", dev->children.load());
+    (void)mirhi_device_set_submit_thread(dev, 0);
     (void)sync_all_lanes(dev);
     for (size_t i = 1; i < dev->lanes.size(); i++) (void)hipStreamDestroy(dev->lanes[i]);
     for (auto& p : dev->pending) { if (p.start != dev->base_stop) (void)hipEventDestroy(p.start); if (p.stop != dev->base_stop) (void)hipEventDestroy(p.stop); }
@@ -383,6 +409,7 @@ extern "C" mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t
 extern "C" mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint32_t world) {
     NULL_CHECK(dev, "device");
     if (world == 0 || rank >= world) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: tile split rank %u of %u", rank, world);
+    drain_submits(dev);
     dev->split_rank = rank; dev->split_world = world;
     return MIRHI_OK;
 }
@@ -775,6 +802,7 @@ extern "C" mirhi_result mirhi_cmd_create(mirhi_device* dev, mirhi_cmd** out) {
 extern "C" mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane) {
     NULL_CHECK(cmd, "command buffer");
     if (lane >= cmd->dev->lanes.size()) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lane %u of %zu", lane, cmd->dev->lanes.size());
+    drain_submits(cmd->dev);
     if (cmd->last_stream) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
     HIP_TRY(hipStreamSynchronize(cmd->dev->lanes[cmd->lane < cmd->dev->lanes.size() ? cmd->lane : 0]));
     cmd->pending = false;
@@ -803,6 +831,7 @@ static void reset_recording(mirhi_cmd* c) {
 static mirhi_result begin_common(mirhi_cmd* cmd, bool one_time) {
     NULL_CHECK(cmd, "command buffer");
     if (cmd->state == CMD_RECORDING) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer is already recording");
+    while (cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     reset_recording(cmd);          // implicit reset, as with RESET_COMMAND_BUFFER pools (command.rs:89-106)
     cmd->state = CMD_RECORDING;
     cmd->one_time = one_time;
@@ -812,6 +841,7 @@ extern "C" mirhi_result mirhi_cmd_begin(mirhi_cmd* cmd) { return begin_common(cm
 extern "C" mirhi_result mirhi_cmd_begin_reusable(mirhi_cmd* cmd) { return begin_common(cmd, false); }
 extern "C" mirhi_result mirhi_cmd_reset(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
+    while (cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     reset_recording(cmd);
     cmd->state = CMD_INITIAL;
     return MIRHI_OK;
@@ -1200,7 +1230,7 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool sprea
 // Sizes the workspace of a recorded command buffer and builds its launch plan.  Runs at end() -- unless the recording is the one the
 // current plan was built from -- and again in front of a submit when an earlier submission exhausted the bin pool
 // (Workspace::grow_pool) or showed a spread-out mesh (Workspace::replan).
-static mirhi_result build_plan(mirhi_cmd* cmd);
+static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit = false);
 
 static bool same_target(const RecordedPass::Target& a, const RecordedPass::Target& b) {
     return a.ptr == b.ptr && a.width == b.width && a.height == b.height && a.format == b.format;
@@ -1227,7 +1257,9 @@ static bool same_recording(const std::vector<RecordedPass>& a, const std::vector
 
 // The workspace of a command buffer that may still be executing must not be touched: Vulkan forbids re-recording a pending command
 // buffer, this build waits for it.  A frame loop that waits on its in-flight fence first (renderer.rs:371-374) never waits here.
-static mirhi_result settle_pending(mirhi_cmd* cmd) {
+static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit = false) {
+    // (submit thread on: not before its queued submissions have been issued -- unless this IS the submit thread, re-planning the job it holds)
+    while (!in_submit && cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     if (!cmd->pending) return MIRHI_OK;
     mirhi_device* dev = cmd->dev;
     bool live = false;
@@ -1302,13 +1334,13 @@ static mirhi_result pblock_commit(Workspace& w, hipStream_t stream) {
     return MIRHI_OK;
 }
 
-static mirhi_result build_plan(mirhi_cmd* cmd) {
+static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     mirhi_device* dev = cmd->dev;
     HIP_TRY(hipSetDevice(dev->ordinal));
     if (cmd->lane >= dev->lanes.size()) cmd->lane = 0;
     hipStream_t stream = dev->lanes[cmd->lane];
     cmd->plan_valid = false;
-    { mirhi_result rs = settle_pending(cmd); if (rs != MIRHI_OK) return rs; }
+    { mirhi_result rs = settle_pending(cmd, in_submit); if (rs != MIRHI_OK) return rs; }
     {
         uint64_t tris_now = 0;
         for (auto& pass : cmd->passes) tris_now += pass.total_tris - pass.first_tri;
@@ -1663,6 +1695,57 @@ static void release_attachments(mirhi_device* dev, const mirhi_cmd* c, uint64_t 
     for_each_attachment(dev, c, [&](mirhi_image* img) { if (img->last_cmd == c && img->last_seq == seq) { img->last_stream = nullptr; img->last_cmd = nullptr; } });
 }
 
+static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence);
+
+static void submit_thread_main(mirhi_device* dev) {
+    (void)hipSetDevice(dev->ordinal);
+    uint64_t taken = dev->sq_done.load(std::memory_order_acquire);      // (the thread may have been stopped and started again: the ring goes on where it was)
+    for (;;) {
+        uint32_t idle = 0;
+        while (dev->sq_pushed.load(std::memory_order_acquire) == taken) {
+            if (dev->sq_stop.load(std::memory_order_acquire)) return;
+            cpu_relax();
+            if (++idle > 40000u) {                    // ~100 us without work: sleep until the next submit
+                std::unique_lock<std::mutex> lk(dev->sq_mu);
+                dev->sq_sleeping.store(true, std::memory_order_seq_cst);
+                dev->sq_cv.wait(lk, [&] { return dev->sq_pushed.load(std::memory_order_acquire) != taken || dev->sq_stop.load(std::memory_order_acquire); });
+                dev->sq_sleeping.store(false, std::memory_order_seq_cst);
+                idle = 0;
+            }
+        }
+        mirhi_device::SubmitJob& job = dev->sq_ring[taken % mirhi_device::SQ_SLOTS];
+        const mirhi_result rc = submit_now(dev, job.n, job.cmds, job.fence);
+        if (rc != MIRHI_OK) {
+            // the caller returned long ago: the failure is reported where the submission's completion is asked for
+            std::lock_guard<std::mutex> lock(dev->mu);
+            if (job.fence) { job.fence->deferred = rc; job.fence->deferred_msg = g_last_error; job.fence->pending = true; }
+            else { dev->deferred = rc; dev->deferred_msg = g_last_error; }
+        }
+        if (job.fence) job.fence->issued.store(true, std::memory_order_release);
+        for (uint32_t i = 0; i < job.n; i++) job.cmds[i]->queued.fetch_sub(1, std::memory_order_release);
+        taken++;
+        dev->sq_done.store(taken, std::memory_order_release);
+    }
+}
+
+extern "C" mirhi_result mirhi_device_set_submit_thread(mirhi_device* dev, uint32_t enable) {
+    NULL_CHECK(dev, "device");
+    if ((enable != 0) == dev->sq_on) return MIRHI_OK;
+    if (enable) {
+        dev->sq_stop.store(false);
+        try { dev->sq_thread = std::thread(submit_thread_main, dev); }
+        catch (...) { return fail(MIRHI_ERR_DEVICE, "Vulkan error: could not start the submit thread"); }
+        dev->sq_on = true;
+    } else {
+        drain_submits(dev);
+        { std::lock_guard<std::mutex> lk(dev->sq_mu); dev->sq_stop.store(true); }
+        dev->sq_cv.notify_all();
+        if (dev->sq_thread.joinable()) dev->sq_thread.join();
+        dev->sq_on = false;
+    }
+    return MIRHI_OK;
+}
+
 extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence) {
     NULL_CHECK(dev, "device");
     if (cmd_count) NULL_CHECK(cmds, "cmds");
@@ -1672,13 +1755,34 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         if (cmds[i]->state != CMD_EXECUTABLE) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer %u is not in the executable state (call end())", i);
     }
     if (fence && fence->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: fence belongs to another device");
+    constexpr uint32_t JOB_CMDS = sizeof(mirhi_device::SubmitJob::cmds) / sizeof(mirhi_cmd*);
+    if (!dev->sq_on || cmd_count > JOB_CMDS) {
+        drain_submits(dev);
+        return submit_now(dev, cmd_count, cmds, fence);
+    }
+    // Submit thread on: the job is queued, the launches happen there.  What the caller may look at next is set here, in its own thread.
+    const uint64_t slot = dev->sq_pushed.load(std::memory_order_relaxed);
+    while (slot - dev->sq_done.load(std::memory_order_acquire) >= mirhi_device::SQ_SLOTS) cpu_relax();
+    mirhi_device::SubmitJob& job = dev->sq_ring[slot % mirhi_device::SQ_SLOTS];
+    job.n = cmd_count; job.fence = fence;
+    for (uint32_t i = 0; i < cmd_count; i++) { job.cmds[i] = cmds[i]; cmds[i]->queued.fetch_add(1, std::memory_order_relaxed); }
+    if (fence) { fence->issued.store(false, std::memory_order_relaxed); fence->pending = true; fence->signaled = false; }
+    dev->sq_pushed.store(slot + 1, std::memory_order_seq_cst);
+    if (dev->sq_sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(dev->sq_mu); dev->sq_cv.notify_one(); }
+    return MIRHI_OK;
+}
+
+static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence) {
     HIP_TRY(hipSetDevice(dev->ordinal));
     for (uint32_t i = 0; i < cmd_count; i++)
         if ((cmds[i]->ws.grow_pool && !getenv("MIRHI_POOL_PAGES")) || cmds[i]->ws.replan) {   // an earlier submission ran out of bin pages (a bigger pool, the same plan) or showed a spread-out mesh (one team)
-            const mirhi_result rp = build_plan(cmds[i]);
+            const mirhi_result rp = build_plan(cmds[i], true);
             if (rp != MIRHI_OK) return rp;
         }
-    std::lock_guard<std::mutex> lock(dev->mu);
+    // dev->mu guards the bookkeeping (unchecked list, statistics, attachment ordering, timed-dispatch events), not the launches: with
+    // the submit thread on, the render thread must be able to complete a fence while this thread is inside hipLaunchKernel
+    std::unique_lock<std::mutex> lock(dev->mu);
+    const bool keep_locked = dev->profiling != 0;
     // Batched form: the command buffers of one submit, when each is one plain rendering scope of the same shape and kernel variants
     // (the frames of a frame loop), share one vertex, one geometry and one raster launch on the first one's queue lane -- the
     // ramp-up and drain of a kernel and the latency chain of the geometry kernel are paid once per batch, not once per frame.
@@ -1728,9 +1832,12 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += c->plan[0].total_tris;
         }
-        HIP_TRY(launch_vertex_batch(P, dp, cmd_count, stream));
-        HIP_TRY(launch_geometry_batch(P, dp, cmd_count, stream));
-        HIP_TRY(launch_raster_batch(P, dp, big, cmd_count, cmds[0]->plan_programs[0], stream, fence_stop));
+        if (!keep_locked) lock.unlock();
+        hipError_t le = launch_vertex_batch(P, dp, cmd_count, stream);
+        if (le == hipSuccess) le = launch_geometry_batch(P, dp, cmd_count, stream);
+        if (le == hipSuccess) le = launch_raster_batch(P, dp, big, cmd_count, cmds[0]->plan_programs[0], stream, fence_stop);
+        if (!keep_locked) lock.lock();
+        HIP_TRY(le);
         fence_attached = fence_stop != nullptr;
     }
     for (uint32_t i = 0; !batched && i < cmd_count; i++) {
@@ -1760,8 +1867,11 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
                 if (P.vs_total_slots && (r = timing_begin(dev, MIRHI_KERNEL_VERTEX, c->lane, &tv)) != MIRHI_OK) return r;
                 if (P.total_slots && (r = timing_begin(dev, MIRHI_KERNEL_GEOMETRY, c->lane, &tg)) != MIRHI_OK) return r;
             }
-            HIP_TRY(launch_vertex(P, dp, stream, tv));
-            HIP_TRY(launch_geometry(P, dp, stream, tg));
+            if (!keep_locked) lock.unlock();
+            hipError_t le = launch_vertex(P, dp, stream, tv);
+            if (le == hipSuccess) le = launch_geometry(P, dp, stream, tg);
+            if (!keep_locked) lock.lock();
+            HIP_TRY(le);
             const bool has_tiles = P.tile_row_end > P.tile_row_begin && P.tiles_x;
             const uint32_t* winners = nullptr;
             if (counted && has_tiles && !P.ordered_recs) {          // (ordered -- blended -- segments are not counted)
@@ -1782,7 +1892,10 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
             }
             if (timed && has_tiles) { mirhi_result r = timing_begin(dev, MIRHI_KERNEL_RASTER, c->lane, &tr); if (r != MIRHI_OK) return r; }
             if (fence_stop && i + 1 == cmd_count && pi + 1 == c->plan.size() && has_tiles) { tr.stop = fence_stop; fence_attached = true; }   // (never together with `timed`)
-            HIP_TRY(launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr));
+            if (!keep_locked) lock.unlock();
+            le = launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr);
+            if (!keep_locked) lock.lock();
+            HIP_TRY(le);
             if (winners) HIP_TRY(launch_winner_count(winners, P.width * P.height, dev->frag_stats, stream));
             dev->stats.frames_submitted++;
             dev->stats.triangles_submitted += P.total_tris;
@@ -1877,6 +1990,14 @@ static mirhi_result fence_complete(mirhi_fence* f) {
 extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
     NULL_CHECK(f, "fence");
     if (f->signaled) return MIRHI_OK;
+    if (f->pending && !f->issued.load(std::memory_order_acquire)) {
+        // its submission still waits in the submit thread's queue (microseconds): the event is recorded when it is issued
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::nanoseconds(timeout_ns < 4000000000ull ? timeout_ns : 4000000000ull);
+        for (uint32_t it = 0; !f->issued.load(std::memory_order_acquire); it++) {
+            cpu_relax();
+            if (timeout_ns != UINT64_MAX && (it & 255u) == 255u && std::chrono::steady_clock::now() >= deadline) return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        }
+    }
     if (!f->pending) {
         // unsignaled and nothing submitted: Vulkan would block until the timeout
         if (timeout_ns == UINT64_MAX) return fail(MIRHI_ERR_DEVICE, "Vulkan error: waiting forever on a fence that was never submitted");
@@ -1892,6 +2013,8 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
             if (e == hipSuccess) return fence_complete(f);
             if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery");
             (void)hipGetLastError();
+            // (a query takes the runtime's locks: back to back from this thread it starves the thread that is launching)
+            for (int k = 0; k < 16; k++) cpu_relax();
             if ((it & 63u) == 63u && std::chrono::steady_clock::now() >= spin_until) break;
         }
         HIP_TRY(hipEventSynchronize(f->event));
@@ -1910,6 +2033,7 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
 extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     if (f->pending) {   // resetting a fence that is still in flight is invalid in Vulkan; drain it first
+        while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
         HIP_TRY(hipSetDevice(f->dev->ordinal));
         HIP_TRY(hipEventSynchronize(f->event));
         (void)fence_complete(f);
@@ -1920,7 +2044,7 @@ extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
 extern "C" mirhi_result mirhi_fence_status(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     if (f->signaled) return MIRHI_OK;
-    if (!f->pending) return MIRHI_NOT_READY;
+    if (!f->pending || !f->issued.load(std::memory_order_acquire)) return MIRHI_NOT_READY;
     (void)hipSetDevice(f->dev->ordinal);
     hipError_t e = hipEventQuery(f->event);
     if (e == hipSuccess) { (void)fence_complete(f); return MIRHI_OK; }
@@ -1930,6 +2054,7 @@ extern "C" mirhi_result mirhi_fence_status(mirhi_fence* f) {
 extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     (void)hipSetDevice(f->dev->ordinal);
+    while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
     if (f->pending) (void)hipEventSynchronize(f->event);
     if (f->event) (void)hipEventDestroy(f->event);
     if (f->join) (void)hipEventDestroy(f->join);
@@ -1944,6 +2069,7 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
 // ------------------------------------------------------------------------------------------------
 extern "C" mirhi_result mirhi_device_set_profiling(mirhi_device* dev, uint32_t enable) {
     NULL_CHECK(dev, "device");
+    drain_submits(dev);
     std::lock_guard<std::mutex> lock(dev->mu);
     dev->profiling = enable & (MIRHI_PROFILE_TIMING | MIRHI_PROFILE_FRAGMENTS | 0xFF00u);
     return MIRHI_OK;
@@ -1972,6 +2098,7 @@ static mirhi_result drain_events(mirhi_device* dev) {
 extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel_id kernel, double* total_ms, uint64_t* launches) {
     NULL_CHECK(dev, "device");
     if ((int)kernel < 0 || (int)kernel >= MIRHI_KERNEL_COUNT) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown kernel id %d", (int)kernel);
+    drain_submits(dev);
     std::lock_guard<std::mutex> lock(dev->mu);
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
@@ -1981,6 +2108,7 @@ extern "C" mirhi_result mirhi_device_kernel_time(mirhi_device* dev, mirhi_kernel
 }
 extern "C" mirhi_result mirhi_device_timeline(mirhi_device* dev, mirhi_dispatch_time* out, uint32_t capacity, uint32_t* count) {
     NULL_CHECK(dev, "device"); NULL_CHECK(count, "count");
+    drain_submits(dev);
     std::lock_guard<std::mutex> lock(dev->mu);
     mirhi_result r = drain_events(dev);
     if (r != MIRHI_OK) return r;
@@ -2016,6 +2144,7 @@ extern "C" mirhi_result mirhi_device_reset_kernel_times(mirhi_device* dev) {
 }
 extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out) {
     NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    drain_submits(dev);
     std::lock_guard<std::mutex> lock(dev->mu);
     *out = dev->stats;
     return MIRHI_OK;
@@ -2133,6 +2262,7 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
     if (algo != MIRHI_GATHER_DIRECT && algo != MIRHI_GATHER_BROADCAST) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown gather algorithm %d", (int)algo);
     if (dev->split_world != comm->world || dev->split_rank != comm->rank)
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
+    drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
     hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
     hipStream_t stream = comm->stream;

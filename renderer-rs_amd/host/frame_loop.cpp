@@ -103,7 +103,10 @@ extern "C" mirhi_result mirhost_frame_loop_create(mirhi_device* dev, const mirho
     for (uint32_t i = 0; i < desc->image_count; i++) if (!desc->images[i]) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: images[i] is null");
     for (uint32_t i = 0; i < desc->draw_count; i++)
         if (!desc->draws[i].pipeline || !desc->draws[i].vertex_buffer) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: a draw needs a pipeline and a vertex buffer");
-    try { *out = new mirhost_frame_loop(dev, *desc); }
+    try {
+        *out = new mirhost_frame_loop(dev, *desc);
+        if (desc->submit_thread) (*out)->device->set_submit_thread(true);
+    }
     catch (const mirhi::RhiError& e) { return fail(e.code, e.what()); }
     catch (const std::exception& e) { return fail(MIRHI_ERR_ALLOCATOR, e.what()); }
     return MIRHI_OK;
@@ -138,6 +141,7 @@ extern "C" mirhi_result mirhost_frame_loop_phase_seconds(mirhost_frame_loop* loo
 extern "C" mirhi_result mirhost_frame_loop_destroy(mirhost_frame_loop* loop) {
     if (!loop) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: loop is null");
     try { loop->frames.wait_for_all_frames(); } catch (...) {}
+    if (loop->desc.submit_thread) { try { loop->device->set_submit_thread(false); } catch (...) {} }
     delete loop;
     return MIRHI_OK;
 }

@@ -206,6 +206,8 @@ public:
     ~Device() { if (h_ && owned_) mirhi_device_destroy(h_); }
     mirhi_device* handle() const { return h_; }
     void wait_idle() const { check(mirhi_device_wait_idle(h_)); }   // device.rs:290-293
+    void set_queue_lanes(uint32_t lanes) const { check(mirhi_device_set_queue_lanes(h_, lanes)); }
+    void set_submit_thread(bool enable) const { check(mirhi_device_set_submit_thread(h_, enable ? 1u : 0u)); }   // vkQueueSubmit returns at once (include/mirhi.h)
 private:
     explicit Device(mirhi_device* h) : h_(h) {}
     mirhi_device* h_;

@@ -64,8 +64,8 @@ def test_rerecorded_frames_with_changing_uniform_and_triangle_count(mirhi, oracl
     dev.destroy()
 
 
-@pytest.mark.parametrize("frames_in_flight,lanes", [(2, 2), (2, 1), (3, 4)])
-def test_native_frame_loop_matches_the_oracle(mirhi, oracle, scenes, frames_in_flight, lanes):
+@pytest.mark.parametrize("frames_in_flight,lanes,submit_thread", [(2, 2, False), (2, 1, False), (3, 4, False), (2, 2, True), (4, 4, True)])
+def test_native_frame_loop_matches_the_oracle(mirhi, oracle, scenes, frames_in_flight, lanes, submit_thread):
     """libmirhost.so (Renderer::render_frame natively, include/mirhost.h): after n frames the image rendered last is the oracle's
     frame -- with the triangle count changing every frame (vary_triangles = 5: frame f draws count - 3 * (f % 5) vertices), so the
     launch plan is rebuilt in every end(), and without (the plan cache path)."""
@@ -77,7 +77,7 @@ def test_native_frame_loop_matches_the_oracle(mirhi, oracle, scenes, frames_in_f
         res = mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB)
         images = [mirhi.Image(dev, scene.width, scene.height, mirhi.Format.B8G8R8A8_SRGB) for _ in range(frames_in_flight + 1)]
         for vary, n in ((0, 7), (5, 9), (5, 13)):
-            loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=frames_in_flight, vary_triangles=vary)
+            loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=frames_in_flight, vary_triangles=vary, submit_thread=submit_thread)
             loop.run(n)
             img, rendered = loop.last_image()
             assert rendered == n
@@ -154,4 +154,40 @@ def test_dependent_command_buffers_of_one_submit_are_not_batched(mirhi, oracle, 
     assert err < 1e-4, f"LOAD after CLEAR in one submit: max |dRGB| = {err}"
     rb.color = None                                          # (the target is shared: ra's destroy() takes it down)
     ra.destroy(); rb.destroy(); fence.destroy()
+    dev.destroy()
+
+
+def test_submit_thread_keeps_fence_and_error_semantics(mirhi, oracle, scenes):
+    """mirhi_device_set_submit_thread: submit() returns before the launches are made.  A fence still waits for its own submission, status
+    queries say NOT_READY until then, wait_idle / read-backs see every queued frame, a device-side failure (big-list overflow forced by a
+    tiny pool) still surfaces at the fence, and switching the thread off again leaves a working device."""
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(2)
+    dev.set_submit_thread(True)
+    scene = scenes.random_triangles(5000, 640, 360, seed=9)
+    ref = oracle.render(scene, want_bgra8=False)
+    slots = [mirhi.SceneResources(dev, scene, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True) for _ in range(2)]
+    fences = [mirhi.Fence(dev) for _ in range(2)]
+    for it in range(40):
+        k = it % 2
+        if it >= 2:
+            fences[k].wait(); fences[k].reset()
+        slots[k].cmd.reset(); slots[k].record()
+        slots[k].render(fences[k])
+    for k in range(2):
+        fences[k].wait()
+        assert fences[k].is_signaled()
+        assert np.array_equal(slots[k].read()["prim"], ref["prim"])
+    # submissions without a fence: wait_idle sees them all
+    for it in range(16):
+        slots[it % 2].render()
+    dev.wait_idle()
+    assert dev.stats().frames_submitted >= 56
+    dev.set_submit_thread(False)
+    slots[0].render(); dev.wait_idle()
+    assert np.array_equal(slots[0].read()["prim"], ref["prim"])
+    for sl in slots:
+        sl.destroy()
+    for f in fences:
+        f.destroy()
     dev.destroy()

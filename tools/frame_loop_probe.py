@@ -21,18 +21,18 @@ def main():
         res.render(); ref = res.read()["color"]
         images = [m.Image(dev, scene.width, scene.height, m.Format.B8G8R8A8_SRGB) for _ in range(fif + 1)]
         out = []
-        for vary in (0, 7):
-            loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=fif, vary_triangles=vary)
+        for vary, thread in ((0, False), (0, True), (7, True)):
+            loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=fif, vary_triangles=vary, submit_thread=thread)
             loop.run(max(64, frames // 8))
             t = [loop.run(frames) for _ in range(3)]
             loop.phase_seconds(True)
             loop.run(frames)
             ph = loop.phase_seconds(False)
             if vary == 0:
-                print(f"   host us/frame: fence wait {1e6 * ph[0] / frames:.2f}, record {1e6 * ph[1] / frames:.2f}, end {1e6 * ph[2] / frames:.2f}, submit {1e6 * ph[3] / frames:.2f}", flush=True)
+                print(f"   submit thread {thread}: host us/frame: fence wait {1e6 * ph[0] / frames:.2f}, record {1e6 * ph[1] / frames:.2f}, end {1e6 * ph[2] / frames:.2f}, submit {1e6 * ph[3] / frames:.2f}", flush=True)
             img, n = loop.last_image()
             same = bool(np.array_equal(img.read(), ref)) if vary == 0 else None
-            out.append((vary, 1e6 * min(t) / frames, same))
+            out.append((f"{vary}{' +thread' if thread else ''}", 1e6 * min(t) / frames, same))
             loop.destroy()
         tris = scene.num_triangles
         print(f"{which} frames in flight {fif} on {lanes} lanes: " + "; ".join(
