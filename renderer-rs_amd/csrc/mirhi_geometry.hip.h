@@ -333,9 +333,12 @@ __device__ __forceinline__ void store_bin_rec(ParamsRef P, uint32_t page, uint32
     dst[1] = make_uint4(c1.y, c1.z, c1.w, idk);
 }
 
-template <uint32_t BATCH>
+// overlap(): work of the caller that depends on nothing here, run exactly once right behind the first batch of returning atomics --
+// a geometry wave is alone on its SIMD (10k triangles are 157 waves on 1024 SIMDs), so whatever it computes while its reservations
+// are on their way through the fabric is free (the flat-colour packing: 1.1 us of a wave's 8.1 us, tools/stamps.py).
+template <uint32_t BATCH, typename Overlap>
 __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, const ScreenTri& t, uint4 (*lds_tri)[3],
-                                                   uint32_t* lds_meta, uint16_t* lds_owner) {
+                                                   uint32_t* lds_meta, uint16_t* lds_owner, Overlap&& overlap) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t hw_xcd = xcd_of_wave();                           // wave-uniform
@@ -367,6 +370,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         const bool act = nb == 1u;
         uint32_t who;
         const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who, xcd);
+        overlap();
         const uint32_t slot = (uint32_t)__shfl((int)raw, (int)(who & 0xFFu)) + (who >> 8);
         // Opening lanes first, as a step of its own: the lane that opens a page and the lanes that wait for it may sit in this very
         // wave, and lanes on the other side of a branch do not run until this side is through.
@@ -425,6 +429,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             }
             slot[k] = reserve_bin_slots(P, act, tile, lane, lt, aux[k], xcd);
         }
+        if (it0 == 0u) overlap();
 #pragma unroll
         for (uint32_t k = 0; k < BATCH; k++) {
             if ((it0 + k) * GEOM_THREADS >= total) continue;
@@ -461,6 +466,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             }
         }
     }
+    if (total == 0u) overlap();     // (no pair in the whole wave: the batch loop never ran)
     __syncthreads();
     if (binned && (lds_meta[lane] >> 31)) spill = true;    // (idempotent resolve: being in some bins as well is harmless)
     if (valid && spill) emit_big(P, t);
@@ -494,11 +500,19 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     }
     DrawRef D = const_draws(H.draws)[lo];
     const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
+    GSTAMP_SYNC(4);
     const uint32_t prim = D.prim_base + tri;
     bool valid = false;
     uint32_t any = 0;
     ScreenTri t;
     f4 c[3];
+    // TRIANGLE program on an sRGB8 target: the vertex colours come in with the positions (same 24-byte vertices, same cache lines --
+    // fetched later they were a second round trip of 0.5 us), the packed flat colour is computed behind the bin reservations
+    // (only in the small-scope register allocation: the occupancy-oriented one has no register to spare and its scopes are meshes)
+    constexpr bool EARLY_COLOUR = WAVES < 7;
+    uint32_t col0[3] = {0u, 0u, 0u};       // colour of vertex 0; is_flat: the other two vertices carry the same bits
+    bool is_flat = true;
+    const bool want_flat = EARLY_COLOUR && P.flat_color != nullptr && D.program == 0;      // (evaluated where it is used in the other allocation)
     bool dropped = false;
     if (D.program == 3) {
         // pixel/model_pbr.hlsl:174-178 `if (baseColor.a < alphaCutoff) discard;` decided per draw where one decision covers it: alpha is
@@ -525,8 +539,15 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
                 c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
             } else {
                 c[k] = vs_position(D, vidx, nullptr);
+                if (EARLY_COLOUR && want_flat) {
+                    const uint8_t* v = D.vb + (size_t)vidx * D.stride;
+                    const uint32_t r = ldu(v, 12), g = ldu(v, 16), b = ldu(v, 20);
+                    if (k == 0) { col0[0] = r; col0[1] = g; col0[2] = b; }
+                    else is_flat = is_flat && r == col0[0] && g == col0[1] && b == col0[2];
+                }
             }
         }
+        GSTAMP_SYNC(5);
         const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
         if (!(o0 & o1 & o2)) {
             any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
@@ -543,15 +564,23 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
             if (any == 0 && in_band) valid = setup_triangle(P, D, c, prim, t);
         }
     }
+    GSTAMP_SYNC(6);
     if (P.prim_draw && tri < D.tri_count) P.prim_draw[prim - P.first_prim] = lo;      // (several draws in the scope)
-    if (P.flat_color && D.program == 0 && (valid || any)) {
-        // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
-        const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
-        const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
-        const uint8_t* v2 = D.vb + (size_t)fetch_index(D, 3u * tri + 2u) * D.stride;
-        const uint32_t r = ldu(v0, 12), g = ldu(v0, 16), b = ldu(v0, 20);
-        const bool flat = r == ldu(v1, 12) && r == ldu(v2, 12) && g == ldu(v1, 16) && g == ldu(v2, 16) && b == ldu(v1, 20) && b == ldu(v2, 20);
-        P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
+    auto flat_colour = [&]() {
+        if (EARLY_COLOUR && want_flat && (valid || any)) {
+            // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
+            P.flat_color[prim] = is_flat ? pack_bgra8_srgb({__uint_as_float(col0[0]), __uint_as_float(col0[1]), __uint_as_float(col0[2]), 1.0f}) : 0u;
+        }
+    };
+    if constexpr (!EARLY_COLOUR) {      // (72-register allocation: as before, in front of the binning -- nothing may stay live across it that need not)
+        if (P.flat_color && D.program == 0 && (valid || any)) {
+            const uint8_t* v0 = D.vb + (size_t)fetch_index(D, 3u * tri) * D.stride;
+            const uint8_t* v1 = D.vb + (size_t)fetch_index(D, 3u * tri + 1u) * D.stride;
+            const uint8_t* v2 = D.vb + (size_t)fetch_index(D, 3u * tri + 2u) * D.stride;
+            const uint32_t r = ldu(v0, 12), g = ldu(v0, 16), b = ldu(v0, 20);
+            const bool flat = r == ldu(v1, 12) && r == ldu(v2, 12) && g == ldu(v1, 16) && g == ldu(v2, 16) && b == ldu(v1, 20) && b == ldu(v2, 20);
+            P.flat_color[prim] = flat ? pack_bgra8_srgb({__uint_as_float(r), __uint_as_float(g), __uint_as_float(b), 1.0f}) : 0u;
+        }
     }
     GSTAMP(1);
     if (P.ordered_recs) {
@@ -564,8 +593,12 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
             uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
             slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u);
         }
-    } else
-    bin_triangle_pairs<(WAVES >= 7 ? 4u : 8u)>(P, valid, t, lds_tri, lds_meta, lds_owner);
+        if constexpr (EARLY_COLOUR) flat_colour();
+    } else if constexpr (EARLY_COLOUR) {
+        bin_triangle_pairs<8u>(P, valid, t, lds_tri, lds_meta, lds_owner, flat_colour);
+    } else {
+        bin_triangle_pairs<4u>(P, valid, t, lds_tri, lds_meta, lds_owner, [] {});
+    }
     GSTAMP(2);
     uint64_t todo = __ballot(any != 0);
     while (todo) {                                   // rare: triangles crossing the near / far / guard planes

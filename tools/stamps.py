@@ -32,13 +32,14 @@ for name, a, b in (("prologue (counters)", 0, 1), ("bin list (fill+raster)", 1, 
     d = d[(s[:, b] > 0) & (s[:, a] > 0)]
     if len(d): print(f"  {name:32s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
 print(f"  wave start spread: p50 {us(np.median(s[:,0]-t0)):.2f} us, max {us((s[:,0]-t0).max()):.2f} us")
-buf = np.zeros(16384 * 4, dtype=np.uint64)
+buf = np.zeros(16384 * 8, dtype=np.uint64)
 L.mirhi_debug_read_geo_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
-g = buf.reshape(-1, 4).astype(np.int64)
+g = buf.reshape(-1, 8).astype(np.int64)
 nb = min(16384, (scene.num_triangles + 63) // 64)
 g = g[:nb]; g = g[g[:, 3] > 0]
 print(f"geometry waves sampled {len(g)}")
-for name, a, b in (("fetch + vs + setup", 0, 1), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
+for name, a, b in (("  entry -> draw descriptor in registers", 0, 4), ("  -> indices + vertices in registers", 4, 5), ("  -> setup done", 5, 6), ("  -> flat colour stored", 6, 1),
+                   ("fetch + vs + setup", 0, 1), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
     d = g[:, b] - g[:, a]
     print(f"  {name:36s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
 res.destroy(); dev.destroy()
