@@ -178,7 +178,8 @@ struct RecordedPass {
 
 // Words of the counter block that never move (a re-recorded frame of another shape finds them where the last frame's kernels
 // left them, re-armed): the two big-list counters, the eight pool counters a cache line apart; the bin counters follow.
-constexpr uint32_t CTR_BIG = 0u, CTR_POOL = 32u, CTR_BINS = CTR_POOL + 8u * (uint32_t)POOL_COUNTER_STRIDE + 32u;
+constexpr uint32_t CTR_BIG = 0u, CTR_POOL = 32u, CTR_ACTIVE = CTR_POOL + 8u * (uint32_t)POOL_COUNTER_STRIDE,   // busy-tile counters: two parities x 8 x 32 words
+                   CTR_BINS = CTR_ACTIVE + 2u * 8u * 32u + 32u;
 
 struct Workspace {
     // Parameter block: everything the kernels read as "parameters" -- two PassParams per scope (big-list counter parity 0 / 1), the
@@ -201,6 +202,11 @@ struct Workspace {
     // 1080p frame: 5,340 pages on 2,040 tiles, raster 41.8 us with two teams, 30.4 us with one; the dancer asset: 1,770 pages, 39 us
     // against 66 us); the plan is rebuilt with one team.
     bool spread = false, replan = false;
+    // Feedback on the wide mesh variant (sixteen waves per tile: raster_body, WIDE): the busy tiles the scope before last reported.  A mesh
+    // scope whose triangles sit in at most WIDE_ON tiles leaves most of the chip without work -- every busy tile then gets four times the
+    // waves; above WIDE_OFF it goes back (hysteresis: a frame loop must not flip between two plans).
+    uint32_t busy_tiles = 0; bool busy_known = false, wide_eligible = false;
+    uint32_t wide = 0;                                         // waves per tile of the wide variant in use: 0 (four waves), 8 or 16
     uint64_t spread_tris = 0;                                  // triangles of the command buffer when `spread` was measured: forgotten when the
                                                                // recorded frame is another one (more than twice / less than half as many)
     uint32_t xcd_tiles_last = 0;                               // tiles of the command buffer's last scope if it uses per-XCD bins, else 0
@@ -1208,9 +1214,10 @@ static void depth_key_setup(PassParams& P, const RecordedPass& pass) {
 //               chain -- which two teams cut (dancer raster 62.6 -> 44.0 us; four teams: 47.4) -- and the geometry kernel as
 //               long as the queue of atomics on the hottest bin counter, which per-XCD counters cut (see reserve_bin_slots).
 //  MIRHI_TP_MAX_AREA (0 = off), MIRHI_TP_DENSITY, MIRHI_RASTER_TEAMS (1 / 2) override for A/B measurements.
-struct RasterMode { uint32_t tp_max_area, teams; bool tri_prog; };
-static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool spread = false) {
-    RasterMode m{0u, 1u, false};
+struct RasterMode { uint32_t tp_max_area, teams; bool tri_prog; bool wide_eligible; bool xcd_bins; uint32_t wide; };
+// wide: what the command buffer's busy-tile feedback asks for (Workspace::wide: 0 / 8 / 16 waves per tile)
+static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool spread = false, uint32_t wide = 0) {
+    RasterMode m{0u, 1u, false, false, false, 0u};
     for (const DrawDesc& dd : pass.draws) m.tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
     PassParams key{};
     depth_key_setup(key, pass);
@@ -1224,6 +1231,18 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool sprea
     m.teams = getenv("MIRHI_RASTER_TEAMS") ? (uint32_t)atoi(getenv("MIRHI_RASTER_TEAMS")) : (avg < 16 ? 2u : 1u);
     if (!(m.tp_max_area && mesh_only && !pass_is_ordered(pass)) || m.teams != 2u) m.teams = 1u;
     if (spread && !getenv("MIRHI_RASTER_TEAMS")) m.teams = 1u;      // measured on an earlier submission of this command buffer (Workspace::spread)
+    // per-XCD bins go with the concentrated-mesh mode (the geometry kernel's counter contention), whichever raster variant then reads them
+    m.xcd_bins = m.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
+    // The wide variants (eight / sixteen waves per tile, raster_body WPT) take over from both the plain and the two-team variant once the
+    // busy-tile count says the mesh sits in few tiles.  MIRHI_RASTER_WIDE = 0 / 8 / 16 forces it (tests, A/B runs); a forced
+    // MIRHI_RASTER_TEAMS = 2 keeps the two teams.
+    m.wide_eligible = m.tp_max_area && mesh_only && !pass_is_ordered(pass) && !pass_is_masked_plain(pass) && !key.pred &&
+                      !(getenv("MIRHI_RASTER_TEAMS") && atoi(getenv("MIRHI_RASTER_TEAMS")) == 2 && !getenv("MIRHI_RASTER_WIDE"));
+    if (m.wide_eligible) {
+        const uint32_t forced = getenv("MIRHI_RASTER_WIDE") ? (uint32_t)atoi(getenv("MIRHI_RASTER_WIDE")) : 0xFFFFFFFFu;
+        m.wide = forced == 0xFFFFFFFFu ? wide : (forced == 0u ? 0u : (forced == 8u ? 8u : 16u));
+        if (m.wide) m.teams = 1u;
+    }
     return m;
 }
 
@@ -1279,9 +1298,9 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
         // no synchronisation, nothing uploaded; only the status words of the previous submission are handed over and re-armed.
         mirhi_result r = settle_pending(cmd);
         if (r != MIRHI_OK) return r;
-        if (cmd->ws.status_host && (cmd->ws.status_host[0] | cmd->ws.status_host[1] | cmd->ws.status_host[2])) {
+        if (cmd->ws.status_host && (cmd->ws.status_host[0] | cmd->ws.status_host[1] | cmd->ws.status_host[2] | cmd->ws.status_host[3])) {
             hand_over_status(cmd);
-            cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0;
+            cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0; cmd->ws.status_host[3] = 0;
         }
         cmd->state = CMD_EXECUTABLE;
         return MIRHI_OK;
@@ -1355,8 +1374,8 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         g.tiles_x = (ci.width + TILE - 1) / TILE; g.tiles_y = (ci.height + TILE - 1) / TILE;
         band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
-        const RasterMode mode = raster_mode(pass, tiles, cmd->ws.spread);
-        g.xcd_bins = mode.teams == 2u && !(getenv("MIRHI_XCD_BINS") && atoi(getenv("MIRHI_XCD_BINS")) == 0);
+        const RasterMode mode = raster_mode(pass, tiles, cmd->ws.spread, cmd->ws.wide);
+        g.xcd_bins = mode.xcd_bins;
         // A tile's bin holds up to BIN_TABLE_ROW pages (4096 records; eight lists of 512 with per-XCD bins) before it spills into
         // the big list, which EVERY tile walks -- the limit costs nothing until it is used: pages come out of one pool, sized by
         // the scope's triangle count, not by tiles x capacity (round 1: 100 MB at 1080p, 400-510 MB at 4K per command buffer).
@@ -1421,7 +1440,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     w.stats_params_valid = false;
     hand_over_status(cmd);          // an earlier submission's status is not lost to the re-arm below (and may ask for a bigger pool: before the flags are cleared)
     w.grow_pool = false; w.replan = false;
-    w.status_host[0] = 0; w.status_host[1] = 0; w.status_host[2] = 0;
+    w.status_host[0] = 0; w.status_host[1] = 0; w.status_host[2] = 0; w.status_host[3] = 0;
     w.big_counts = w.counters + CTR_BIG;
     if (!w.dirty && getenv("MIRHI_VERIFY_IDLE")) {
         // Test hook: what the plan relies on instead of clearing -- every kernel leaves the workspace re-armed -- is checked here, on the
@@ -1431,7 +1450,8 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         HIP_TRY(hipMemcpy(c.data(), w.counters, c.size() * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(t.data(), w.bin_table, t.size() * 4, hipMemcpyDeviceToHost));
         size_t bad_c = 0, bad_t = 0;
-        for (size_t i = 0; i < c.size(); i++) bad_c += (c[i] != 0u && i != (size_t)(CTR_BIG + (w.parity ^ 1u))) ? 1 : 0;
+        for (size_t i = 0; i < c.size(); i++)       // (the busy-tile counters of the last scope are read and re-armed by the next one)
+            bad_c += (c[i] != 0u && i != (size_t)(CTR_BIG + (w.parity ^ 1u)) && !(i >= CTR_ACTIVE && i < CTR_ACTIVE + 2u * 8u * 32u)) ? 1 : 0;
         for (uint32_t v : t) bad_t += v != PAGE_EMPTY ? 1 : 0;
         if (bad_c || bad_t) return fail(MIRHI_ERR_DEVICE, "Vulkan error: workspace not idle between frames: %zu counter words, %zu page-table entries left set", bad_c, bad_t);
     }
@@ -1521,6 +1541,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     w.draws_count = total_draws;
 
     size_t draws_done = 0, jobs_done = 0;
+    bool any_wide_eligible = false;
     cmd->plan.clear(); cmd->plan_programs.clear(); cmd->plan_tris = 0;
     for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
         RecordedPass& pass = cmd->passes[pi];
@@ -1575,10 +1596,12 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
             P.flat_color = (tri_prog && ci.format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
         }
         {
-            const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0), w.spread);
+            const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0), w.spread, w.wide);
             P.tp_max_area = mode.tp_max_area;
             P.alpha_scope = pass_is_masked_plain(pass) ? 1u : 0u;
             P.raster_teams = mode.teams;
+            P.raster_wide = mode.wide;          // waves per tile of the wide variants: 0 (four waves), 8 or 16
+            any_wide_eligible |= mode.wide_eligible;
             P.sub_cap = g.sub_cap;
             P.count_stride = g.xcd_bins ? (uint32_t)max_tiles : 0u;
         }
@@ -1612,9 +1635,12 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
             PassParams Q = P;
             Q.big_count = w.big_counts + parity;
             Q.big_count_next = w.big_counts + (parity ^ 1u);
+            Q.active = w.counters + CTR_ACTIVE + parity * 8u * 32u;
+            Q.active_prev = w.counters + CTR_ACTIVE + (parity ^ 1u) * 8u * 32u;
             memcpy(w.pimage.data() + (2 * pi + parity) * sizeof(PassParams), &Q, sizeof Q);
         }
     }
+    w.wide_eligible = any_wide_eligible;
     if ((r = pblock_commit(w, stream)) != MIRHI_OK) return r;
     if (!w.pblock_direct) { cmd->last_stream = stream; cmd->pending = true; }     // (the copy is in the lane's stream)
     cmd->planned = cmd->passes;
@@ -1643,6 +1669,8 @@ static mirhi_result stats_params_for(mirhi_cmd* c) {
             PassParams P = P0;
             P.big_count = w.big_counts + parity;
             P.big_count_next = w.big_counts + (parity ^ 1u);
+            P.active = w.counters + CTR_ACTIVE + parity * 8u * 32u;
+            P.active_prev = w.counters + CTR_ACTIVE + (parity ^ 1u) * 8u * 32u;
             P.prim_out = w.stats_prim;
             copies.push_back(P);
         }
@@ -1945,6 +1973,20 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
             // not an error: the records went to the big list and the frame is complete; the pool is doubled in front of the next submit
             c->ws.grow_pool = true;
             if (c->ws.pool_scale < 64u) c->ws.pool_scale *= 2u;
+        }
+        if (c->ws.status_host[3] & 0x80000000u) {
+            // busy tiles of the scope before this one: few of them = a mesh in a part of the frame = the wide variant (and back), see Workspace::wide
+            // Sixteen waves per tile are one workgroup per CU at a time: for up to ~240 busy tiles (the dancer asset: 232; raster 39 -> 30 us);
+            // eight waves are two per CU: up to ~512 (the 70k-triangle sphere: 419; 32.5 -> 24.8 us, sixteen: 31.7 in two rounds).  Hysteresis
+            // of a quarter so that a frame loop does not flip between two plans.
+            c->ws.busy_tiles = c->ws.status_host[3] & 0x7FFFFFFFu; c->ws.busy_known = true;
+            const uint32_t b = c->ws.busy_tiles, cur = c->ws.wide;
+            uint32_t want = cur;
+            if (b == 0u) want = 0u;
+            else if (b <= (cur == 16u ? 300u : 240u)) want = 16u;
+            else if (b <= (cur == 8u ? 640u : 512u)) want = 8u;
+            else want = 0u;
+            if (want != cur && c->ws.wide_eligible && !getenv("MIRHI_RASTER_WIDE")) { c->ws.wide = want; c->ws.replan = true; }
         }
         if (!c->ws.spread && c->ws.xcd_tiles_last && c->ws.status_host[2] > 2u * c->ws.xcd_tiles_last) { c->ws.spread = true; c->ws.replan = true; c->ws.spread_tris = c->plan_tris; }
         if (c->ws.status_host[0] & (STATUS_PAGE_TIMEOUT | STATUS_BIG_OVERFLOW)) c->ws.dirty = true;     // counters / page table are cleared before the next frame

@@ -6,13 +6,13 @@
 #ifdef MIRHI_STAMPS
 // Diagnostic build only (build.py --stamps -> libmirhi_stamps.so): per-wave s_memtime stamps at phase
 // boundaries, written to a buffer nothing else reads.  Never compiled into libmirhi.so.
-__device__ uint64_t g_stamps[16384 * 8];
+__device__ uint64_t g_stamps[32768 * 8];
 __device__ uint64_t g_stamps_geo[16384 * 8];
 #define GSTAMP(k) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 16384u) g_stamps_geo[blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 // diagnostic only: wait for everything outstanding, then stamp (where did the time go: this changes the schedule it measures)
 #define GSTAMP_SYNC(k) do { __builtin_amdgcn_s_waitcnt(0); GSTAMP(k); } while (0)
 #define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
-    if (wv < 16384u) g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    if (wv < 32768u) g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 // instruction-count attribution: the raster kernel returns after stage g_stage_limit (1 prologue, 2 fill of the first
 // chunk, 3 both lists); the SQ instruction counters of such runs, differenced, give the dynamic cost of each stage
 __device__ uint32_t g_stage_limit;

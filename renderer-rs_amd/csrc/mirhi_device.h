@@ -155,6 +155,11 @@ struct PassParams {
     // bin_cap, and the first page of every tile's single list has a fixed place in the pool (page = tile): the common bin
     // needs neither an allocation nor a table entry.
     uint32_t sub_cap, count_stride;
+    uint32_t raster_wide;             // 1: the wide mesh variant, sixteen waves per tile (host-side choice from the busy-tile count, see raster_body)
+    // Busy-tile count (feedback for that choice): every raster workgroup whose tile holds something adds 1 to active[(tile & 7) * 32] (eight
+    // counters, one per XCD residue, a cache line apart); the workgroup of tile 0 reports the sum of the PREVIOUS scope's counters
+    // (active_prev: the other parity, complete by then) in status[3] and re-arms them.
+    uint32_t* active; uint32_t* active_prev;
     // ordered segments (blending; any depth state whose result depends on the order of all fragments): the geometry kernel
     // writes triangle t of the segment to ordered_recs[t] instead of binning it, the ordered kernel walks that array
     TriRec*  ordered_recs; uint32_t ordered_first, ordered_count;
@@ -162,7 +167,8 @@ struct PassParams {
     uint32_t blend[8];                // enable, src colour, dst colour, colour op, src alpha, dst alpha, alpha op, write mask
     uint32_t alpha_scope;             // 1: a plain (bins + depth key) scope whose pipelines set fragment_discard_enable: records of draws whose texel
                                       // alpha straddles the material's cutoff are resolved triangle-parallel with the alpha test per pixel (raster_small_masked)
-    uint32_t* status;                 // pinned host memory: [0] status bits (atomicOr), [1] big-list length, [2] dynamic pages of the last scope
+    uint32_t* status;                 // pinned host memory: [0] status bits (atomicOr), [1] big-list length, [2] dynamic pages of the last scope,
+                                      // [3] busy tiles of the scope before it | 0x80000000
     unsigned long long* frag_stats;   // device counters of the statistics pass (never touched by geometry / raster kernels): [0] pixels that
                                       // ran a fragment program (winners of the depth resolve), [1] fragments covered before the depth test
 };

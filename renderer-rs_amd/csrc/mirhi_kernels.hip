@@ -101,7 +101,16 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
-    if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream, t);          // (the host keeps tp_max_area = 0 for predicate scopes)
+    if (P.raster_wide && !P.pred && P.tp_max_area && P.raster_teams != 2u && !P.alpha_scope && (programs == 2 || programs >= 4) && P.xcd_swizzle <= 1u) {
+        // the wide mesh variants: eight or sixteen waves per tile (host-side choice, PassParams::raster_wide = waves per tile)
+        const bool w16 = P.raster_wide >= 16u;
+        const dim3 wb(w16 ? 1024 : 512);
+#define MIRHI_WIDE(PR, KE) do { if (w16) MIRHI_LAUNCH((raster_kernel_wide<PR, KE, 16>), grid, wb, stream, t, dev_params, H); else MIRHI_LAUNCH((raster_kernel_wide<PR, KE, 8>), grid, wb, stream, t, dev_params, H); } while (0)
+        if (programs == 2) { if (plain) MIRHI_WIDE(2, 0); else MIRHI_WIDE(2, 1); }
+        else { if (plain) MIRHI_WIDE(4, 0); else MIRHI_WIDE(4, 1); }
+#undef MIRHI_WIDE
+    }
+    else if (P.pred) launch_raster_k<2, 0>(dev_params, H, programs, grid, stream, t);          // (the host keeps tp_max_area = 0 for predicate scopes)
     else if (P.tp_max_area && P.raster_teams == 2u && (programs == 2 || programs >= 4)) {
         if (plain) launch_raster_k<0, 1, 2>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); else launch_raster_k<1, 1, 2>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u);
     }
@@ -118,7 +127,8 @@ uint64_t raster_variant_key(const PassParams& P, uint32_t programs) {
     const uint32_t teams = (tp && P.raster_teams == 2u && (programs == 2 || programs >= 4)) ? 2u : 1u;
     const uint32_t prog = programs >= 4 ? 4u : programs;
     return (uint64_t)prog | ((uint64_t)keyed << 4) | ((uint64_t)tp << 8) | ((uint64_t)teams << 12) | ((uint64_t)(P.xcd_swizzle > 1u ? 1u : 0u) << 16) |
-           ((uint64_t)P.tiles_x << 20) | ((uint64_t)(P.tile_row_end - P.tile_row_begin) << 36) | ((uint64_t)(P.ordered_recs ? 1u : 0u) << 52);
+           ((uint64_t)P.tiles_x << 20) | ((uint64_t)(P.tile_row_end - P.tile_row_begin) << 36) | ((uint64_t)(P.ordered_recs ? 1u : 0u) << 52) |
+           ((uint64_t)(P.raster_wide >> 3) << 53);
 }
 
 hipError_t launch_vertex_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream) {
@@ -180,7 +190,7 @@ hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* co
     (void)plain;
     return hipGetLastError();
 }
-bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs && !P.alpha_scope; }
+bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs && !P.alpha_scope && !P.raster_wide; }
 
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
@@ -211,7 +221,7 @@ extern "C" int mirhi_debug_clear_stamps() {
     void* p = nullptr;
     hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps));
     if (e != hipSuccess) return (int)e;
-    return (int)hipMemset(p, 0, sizeof(uint64_t) * 16384 * 8);
+    return (int)hipMemset(p, 0, sizeof(uint64_t) * 32768 * 8);
 }
 #endif
 

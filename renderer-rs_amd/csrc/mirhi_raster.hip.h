@@ -211,7 +211,8 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return d;
 }
 
-template <int KEYED, bool BOXED>
+// NB: 8x8 blocks this wave owns -- 4 (a 16x16 quadrant, four waves per tile) or 1 (the wide mesh variant: sixteen waves per tile)
+template <int KEYED, bool BOXED, int NB = 4>
 __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, int32_t ix0, int32_t iy0, float fix0,
                                               float fiy0, ParamsRef P, PixelState& st, uint32_t qbit0) {
     const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
     // pixel centre minus vertex 0, exact in binary32 (see make_tile_rec), for the two columns / rows of blocks
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < NB; b++) {
         const int bx = b & 1, by = b >> 1;
         if (!(m & (qbit0 << (by * 4 + bx)))) continue;
         // edge functions at this block: one shift-add per edge and step (v_lshl_add_u32), no shared shift results
@@ -279,7 +280,7 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
 // too large for the triangle-parallel walk of raster_small_masked): coverage as raster_record, then the fragment program's alpha
 // (pbr_base_alpha: the shading path's bits) on the covered lanes, and only fragments it keeps compete by their depth key.  The
 // triangle's clip positions and texture coordinates are fetched once per record (a uniform address).
-template <int KEYED>
+template <int KEYED, int NB = 4>
 __device__ __forceinline__ void raster_record_masked(const RecRegs& r, int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
                                                      PixelState& st, uint32_t qbit0, uint32_t tx, uint32_t ty) {
     const int32_t A0 = (int32_t)r.w0.w, A1 = (int32_t)r.w1.x, A2 = (int32_t)r.w1.y;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void raster_record_masked(const RecRegs& r, int32_t i
     const float dx0 = fix0 + __uint_as_float(r.w2.y), dy0 = fiy0 + __uint_as_float(r.w2.z);
     const float pxc0 = (float)(tx * TILE + (uint32_t)ix0) + 0.5f, pyc0 = (float)(ty * TILE + (uint32_t)iy0) + 0.5f;
 #pragma unroll 1
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < NB; b++) {
         const int bx = b & 1, by = b >> 1;
         if (!(m & (qbit0 << (by * 4 + bx)))) continue;
         const int32_t S0 = s0 + (A0 * bx + B0 * by) * BLOCK, S1 = s1 + (A1 * bx + B1 * by) * BLOCK, S2 = s2 + (A2 * bx + B2 * by) * BLOCK;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void raster_record_masked(const RecRegs& r, int32_t i
 
 // all records of an LDS chunk: per 64 records one ballot builds the bitmap of records that touch this
 // wave's quadrant; LDS latency of the broadcast record reads is hidden by the other waves of the SIMD
-template <int KEYED, int TP, bool MASKED = false>
+template <int KEYED, int TP, bool MASKED = false, int NB = 4>
 __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_t* lds_box, uint32_t n, uint32_t qmask,
                                              int32_t ix0, int32_t iy0, float fix0, float fiy0, ParamsRef P,
                                              PixelState& st, uint32_t qbit0, uint32_t lane, uint32_t tx = 0u, uint32_t ty = 0u) {
@@ -344,7 +345,7 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
                 const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)mbits) - 1);
                 mbits &= mbits - 1;
                 const RecRegs cur = load_rec(lds_rec, cur_j);
-                raster_record_masked<KEYED>(cur, ix0, iy0, fix0, fiy0, P, st, qbit0, tx, ty);
+                raster_record_masked<KEYED, NB>(cur, ix0, iy0, fix0, fiy0, P, st, qbit0, tx, ty);
             }
         }
         uint64_t bits = __ballot(rel && !boxed && !mrec);
@@ -354,7 +355,7 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
             // at the vector unit's rate on this part, and this loop runs once per record and wave)
             asm("s_bitset0_b64 %0, %1" : "+s"(bits) : "s"(bit));
             const RecRegs cur = load_rec(lds_rec, g + bit);
-            raster_record<KEYED, false>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
+            raster_record<KEYED, false, NB>(cur, 0u, ix0, iy0, fix0, fiy0, P, st, qbit0);
         }
         if (!TP) {   // without the triangle-parallel path, scissor-cut triangles (rare) take the per-pixel box test here
             uint64_t bbits = __ballot(rel && boxed);
@@ -362,7 +363,7 @@ __device__ __forceinline__ void raster_chunk(const uint4* lds_rec, const uint32_
                 const uint32_t cur_j = g + (uint32_t)(__ffsll((long long)bbits) - 1);
                 bbits &= bbits - 1;
                 const RecRegs cur = load_rec(lds_rec, cur_j);
-                raster_record<KEYED, true>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
+                raster_record<KEYED, true, NB>(cur, lds_box[cur_j], ix0, iy0, fix0, fiy0, P, st, qbit0);
             }
         }
     }
@@ -490,7 +491,7 @@ __device__ __forceinline__ void init_key(ParamsRef P, uint32_t px, uint32_t py, 
 // sub-bins before k, so that flat index i lives in sub-bin #{k >= 1 : i >= seg[k]} at offset i - seg[that].  nullptr: a plain list.
 // bins: `list` is the bin pool and flat index i of the tile's bin lives in pool page pages[...] (LDS copy of the tile's page-table
 // row; the first page of a single-list bin is page `tile` itself); otherwise `list` is a plain TriRec array (the big list).
-template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS, bool MASKED = false>
+template <int KEYED, int TP, int CHUNK, int TEAMS, bool BINS, bool MASKED = false, int WPT = 4>
 __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint32_t n_total, uint32_t tile, uint32_t fixed_recs, const uint32_t* pages, const uint32_t* seg, uint4* lds_rec, uint32_t* lds_box,
                                             uint32_t* lds_count, uint32_t& flip, uint32_t team, uint32_t nteams, unsigned long long* lds_key, uint32_t tx, uint32_t ty,
                                             uint32_t qmask, int32_t ix0, int32_t iy0, float fix0, float fiy0,
@@ -498,7 +499,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
                                             uint32_t lane) {
     // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
-    const uint32_t ftid = (tid + 64u * ((tx + ty) & 3u)) & (RASTER_THREADS - 1u);
+    const uint32_t ftid = (tid + 64u * ((tx + ty) & (uint32_t)(WPT - 1))) & ((uint32_t)WPT * 64u - 1u);
     for (uint32_t base0 = 0; base0 < n_total; base0 += (uint32_t)CHUNK * (TEAMS > 1 ? nteams : 1u)) {
         const uint32_t base = base0 + team * (uint32_t)CHUNK;
         // Two staging counters used alternately: the one of this pass was zeroed during the previous pass (or at kernel
@@ -520,7 +521,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             if (BINS) {
                 // flat index -> (list, slot) -> pool page; both words of the record are requested together
                 uint32_t k = 0, j = i;
-                if (TEAMS > 1 && seg) {
+                if ((TEAMS > 1 || WPT > 4) && seg) {
 #pragma unroll
                     for (uint32_t q = 1; q < 8u; q++) k += i >= seg[q] ? 1u : 0u;
                     j = i - seg[k];
@@ -601,7 +602,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         const uint32_t n = *cnt;
         flip ^= 1u;
         if (base0 == 0) { STAMP(5); STAGE_END(2u); }
-        if (n) raster_chunk<KEYED, TP, MASKED>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane, txl, tyl);
+        if (n) raster_chunk<KEYED, TP, MASKED, 16 / WPT>(lds_rec, lds_box, n, qmask, ix0, iy0, fix0, fiy0, P, st, qbit0, lane, txl, tyl);
     }
 }
 
@@ -619,21 +620,32 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
 // MASKEDV: the variant of an alpha-masked scope (PassParams::alpha_scope; PROGS = 4 with TP): carries raster_small_masked and
 // raster_record_masked -- its own variant so that the scopes without masked materials keep their registers (the two paths cost
 // the PROGS = 4 kernels 48-78 scalar registers spilled to vector lanes and 2 % of the dancer asset's frame).
-template <int PROGS, int KEYED, int TP, int TEAMS = 1, bool MASKEDV = false>
+// WIDE (mesh variants, one team): SIXTEEN waves per tile, one 8x8 block each, 1024 records staged per pass.  A mesh that covers a part of
+// the frame (the 70k-triangle sphere: 419 of 2040 tiles hold everything) leaves three quarters of the SIMDs without a wave while every
+// busy tile's four waves walk their four blocks one after the other -- 12.5 us of shading per wave, tools/stamps.py c3 -- at the issue rate
+// of a wave that has its SIMD to itself.  Splitting the tile's PIXELS over four times the waves needs no merge and no atomics (unlike the
+// two-team variant, which splits the records): same staging, same triangle-parallel walk, each wave visits the records that touch its
+// block and shades its 64 pixels.  Chosen by the host from the number of busy tiles the previous frame reported (PassParams::raster_wide).
+template <int PROGS, int KEYED, int TP, int TEAMS = 1, bool MASKEDV = false, int WPT = 4>
 #ifndef MIRHI_PROGS2_WAVES
 #define MIRHI_PROGS2_WAVES 5
 #endif
 __device__ __forceinline__ void raster_body(const PassParams* __restrict__ params, const RasterHead& H) {
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
+    constexpr bool WIDE = WPT > 4;                      // WPT: waves per tile (and team): 4, or 8 / 16 in the wide variants
+    static_assert(WPT == 4 || WPT == 8 || WPT == 16, "waves per tile");
+    static_assert(!WIDE || (TEAMS == 1 && TP != 0 && PROGS >= 2), "the wide variants exist for one-team mesh scopes with the triangle-parallel path");
+    constexpr int NB = 16 / WPT;                        // 8x8 blocks per wave
+    constexpr uint32_t TT = (uint32_t)WPT * 64u;        // lanes per team
     // mesh variants stage with all four waves: their small records are resolved while staging (triangle-parallel), so a
     // hot tile's serial chain is one pass per CHUNK records; the sparse variants keep 192 (LDS per workgroup bounds
     // their 7-8 workgroups per CU)
-    constexpr int CHUNK = (TP && PROGS >= 2) ? RASTER_THREADS : RASTER_CHUNK;
+    constexpr int CHUNK = WIDE ? (int)TT : ((TP && PROGS >= 2) ? RASTER_THREADS : RASTER_CHUNK);
     __shared__ uint4 lds_rec[TEAMS][CHUNK * 4];
     __shared__ unsigned long long lds_key[TP ? TILE * TILE : 1];   // depth keys written by the triangle-parallel path
     __shared__ uint32_t lds_box[TP ? 1 : RASTER_CHUNK];
     __shared__ uint32_t lds_count[TEAMS * 2];
-    const uint32_t tid = threadIdx.x & (RASTER_THREADS - 1u), lane = tid & 63u;       // tid: index within the team
+    const uint32_t tid = threadIdx.x & (TT - 1u), lane = tid & 63u;       // tid: index within the team
     const uint32_t team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index within the team: uniform, keep it in SGPRs
     // (one contiguous band of tiles per XCD measured 20-30 % slower on unevenly covered frames: runs stay interleaved)
@@ -651,20 +663,23 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
         tx = t % H.tiles_x; tyr = t / H.tiles_x;
     }
     const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
-    const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
+    // four waves: wave q owns the 16x16 quadrant q (blocks b: bx = b & 1, by = b >> 1 from its first); eight: the 16x8 strip
+    // (q & 1, q >> 1), two blocks side by side; sixteen: block q (bx = q & 3, by = q >> 2)
+    const int32_t ix0 = WPT == 16 ? (int32_t)((q & 3u) * 8u + (lane & 7u)) : (int32_t)((q & 1u) * 16u + (lane & 7u));
+    const int32_t iy0 = WPT == 16 ? (int32_t)((q >> 2) * 8u + (lane >> 3)) : (WPT == 8 ? (int32_t)((q >> 1) * 8u + (lane >> 3)) : (int32_t)((q >> 1) * 16u + (lane >> 3)));
     const float fix0 = (float)ix0, fiy0 = (float)iy0;
-    // the four 8x8 blocks of quadrant q are bits (2*(q>>1)+by)*4 + 2*(q&1)+bx of the record's block mask
-    const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u);
-    const uint32_t qmask = qbit0 * 0x33u;
+    // the record's block mask has bit by * 4 + bx for block (bx, by) of the tile: the wave's first block, and all of its blocks
+    const uint32_t qbit0 = WPT == 16 ? (1u << q) : (WPT == 8 ? (1u << ((q >> 1) * 4u + (q & 1u) * 2u)) : (1u << ((q >> 1) * 8u + (q & 1u) * 2u)));
+    const uint32_t qmask = WPT == 16 ? qbit0 : (WPT == 8 ? qbit0 * 0x3u : qbit0 * 0x33u);
 
     STAMP(0);
     // both counters are fetched up front so their latencies overlap
     // (the head of the parameters comes by value: the counter loads depend on the kernarg load alone, not on a second hop)
-    __shared__ uint32_t lds_seg[TEAMS > 1 ? 9 : 1];     // two-team variant: records in the per-XCD sub-bins before k; [8] = all
-    const bool xcd_bins = TEAMS > 1 && H.count_stride != 0u;
+    __shared__ uint32_t lds_seg[(TEAMS > 1 || WIDE) ? 9 : 1];     // two-team and wide variants: records in the per-XCD sub-bins before k; [8] = all
+    const bool xcd_bins = (TEAMS > 1 || WIDE) && H.count_stride != 0u;
     uint32_t count_raw = H.bin_count[tile];
     const uint32_t nbig_raw = *H.big_count;
-    if (TEAMS > 1) {
+    if (TEAMS > 1 || WIDE) {
         if (xcd_bins) {
             if (threadIdx.x == 0) {
                 uint32_t c[8];
@@ -703,6 +718,9 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
             P.pool_next[x * (uint32_t)POOL_COUNTER_STRIDE] = 0;
         }
         P.status[2] = pages_used;
+        uint32_t busy = 0;                                  // busy tiles of the previous scope on this workspace (its counters are final)
+        for (uint32_t x = 0; x < 8u; x++) { busy += P.active_prev[x * 32u]; P.active_prev[x * 32u] = 0; }
+        P.status[3] = busy | 0x80000000u;
     }
 
     if (count == 0u && nbig == 0u) {
@@ -715,7 +733,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
         if (write_color || write_depth) {
             const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < NB; b++) {
                 const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
                 if (px >= P.width || py >= P.height) continue;
                 const size_t pix = (size_t)py * P.width + px;
@@ -732,8 +750,9 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     }
 
     if (tid == 0) { lds_count[2u * team] = 0; lds_count[2u * team + 1u] = 0; }      // this team's staging counters (ordered by raster_list's first barrier)
+    if (PROGS >= 2 && tid == 0 && team == 0) __hip_atomic_fetch_add(&P.active[(tile & 7u) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a busy tile; mesh scopes only)
     uint32_t flip = 0;
-    if (TP) for (uint32_t e = tid + team * RASTER_THREADS; e < TILE * TILE; e += RASTER_THREADS * nteams) lds_key[e] = ~0ull;
+    if (TP) for (uint32_t e = tid + team * TT; e < TILE * TILE; e += TT * nteams) lds_key[e] = ~0ull;
     PixelState st;
 #pragma unroll
     for (int b = 0; b < 4; b++) { st.zk[b] = P.init_zk; st.idk[b] = P.init_idk; }
@@ -748,7 +767,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     if (P.depth_load && P.depth && team == 0) { // second scope on a kept depth buffer: keys start from the stored depth (one team's keys)
         const uint32_t px0 = tx * TILE + (uint32_t)ix0, py0 = ty * TILE + (uint32_t)iy0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < NB; b++) {
             const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
             uint32_t zo;
             init_key(P, px, py, px < P.width && py < P.height, st.zk[b], st.idk[b], zo);
@@ -762,7 +781,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // spilled triangles).  Two instantiations of raster_list: one body fed from either source has to hold both record forms in
     // registers on the way to the tile record, which the TRIANGLE-only variants (64 VGPRs) pay with ~20 spills.
     constexpr bool MASKED = MASKEDV && PROGS == 4 && TP != 0;
-    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true, MASKED>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, H.fixed_recs, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    if (count) raster_list<KEYED, TP, CHUNK, TEAMS, true, MASKED, WPT>(reinterpret_cast<const uint4*>(H.bin_pool), count, tile, H.fixed_recs, lds_pages, xcd_bins ? lds_seg : nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
     STAMP(2);
     if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
@@ -772,7 +791,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
     if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;
     // parameters of this phase are (re)read here, see launder_params
-    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false, MASKED>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, 0u, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
+    if (nbig) raster_list<KEYED, TP, CHUNK, TEAMS, false, MASKED, WPT>(reinterpret_cast<const uint4*>(launder_params((ParamsPtr)(uintptr_t)params)->big_recs), nbig, tile, 0u, lds_pages, nullptr, lds_rec[team], lds_box, lds_count + 2u * team, flip, team, nteams, lds_key, tx, ty, qmask, ix0, iy0, fix0, fiy0, P, st,
                                                          qbit0, tid, lane);
 
     STAMP(3);
@@ -782,7 +801,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // merge the pixel-parallel (registers) and triangle-parallel (LDS) results: smaller key wins
     if (TP) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < NB; b++) {
             const unsigned long long kreg = ((unsigned long long)st.zk[b] << 32) | st.idk[b];
             const unsigned long long klds = lds_key[(iy0 + (b >> 1) * BLOCK) * TILE + ix0 + (b & 1) * BLOCK];
             const unsigned long long kmin = klds < kreg ? klds : kreg;
@@ -874,7 +893,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
         }
     }
 #pragma unroll 1
-    for (int b = 0; b < 4; b++) {
+    for (int b = 0; b < NB; b++) {
         if (TEAMS > 1 && !solo && (uint32_t)(b * TEAMS) / 4u != team) continue;      // another team shades this block
         const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
         const bool inb = px < P.width && py < P.height;
@@ -928,6 +947,11 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
 template <int PROGS, int KEYED, int TP, int TEAMS = 1, bool MASKEDV = false>
 __global__ MIRHI_RASTER_BOUNDS void raster_kernel(const PassParams* __restrict__ params, const RasterHead H) {
     raster_body<PROGS, KEYED, TP, TEAMS, MASKEDV>(params, H);
+}
+// the wide mesh variant: sixteen waves per tile (raster_body, WIDE); one workgroup is a CU's four waves per SIMD
+template <int PROGS, int KEYED, int WPT>
+__global__ __launch_bounds__(WPT * 64, (PROGS == 2 && WPT == 16 ? 6 : (PROGS == 2 ? 5 : 4))) void raster_kernel_wide(const PassParams* __restrict__ params, const RasterHead H) {
+    raster_body<PROGS, KEYED, 1, 1, false, WPT>(params, H);
 }
 // up to MAX_BATCH independent rendering scopes of equal shape (the frames of one mirhi_queue_submit): grid (tiles_x, tile rows, scopes).
 // One launch instead of one per frame: the ramp-up and drain of a kernel (5 us of the 11 us an isolated 10k-triangle raster kernel

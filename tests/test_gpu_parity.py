@@ -561,3 +561,81 @@ def test_alpha_masked_mesh_of_small_triangles(mirhi, oracle, device, scenes):
     _check(out, ref, scene.name, depth=True)
     kept = (ref["prim"] >= 200) & (ref["prim"] != 0xFFFFFFFF)
     assert 0.03 < kept.mean() < 0.8         # the discs keep about a fifth of the sheet, holes show what lies behind
+
+
+@pytest.mark.parametrize("waves", [8, 16])
+@pytest.mark.parametrize("case", ["c3", "c3_greater", "c3_two_states", "sphere_small", "textured", "pbr", "mips", "aniso", "multi_draw", "dancer", "dancer_tex", "depth_image",
+                                  "dancer_xcd_bins", "dancer_tex_xcd_bins", "heap_xcd_bins"])
+def test_wide_mesh_variants(mirhi, oracle, device, scenes, case, waves, monkeypatch):
+    """raster_kernel_wide (eight / sixteen waves per tile with two / one 8x8 blocks each, 512 / 1024 records staged per pass; the host picks
+    the first for mesh scopes whose triangles sit in few tiles) forced with MIRHI_RASTER_WIDE -- and, for the two-team candidates, MIRHI_RASTER_TEAMS=1 so that
+    the scope is eligible: plain and generic depth keys, two segments of one scope, the full-featured programs, a stored depth image."""
+    import copy
+    import os
+    monkeypatch.setenv("MIRHI_RASTER_WIDE", str(waves))
+    if not case.endswith("xcd_bins"):                    # (*_xcd_bins: the concentrated-mesh mode keeps its eight per-XCD lists per tile, read by the wide variant)
+        monkeypatch.setenv("MIRHI_RASTER_TEAMS", "1")
+    monkeypatch.setenv("MIRHI_TP_DENSITY", "0")          # (every mesh scope gets the triangle-parallel path the wide variant builds on)
+    dancer = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dancer", "scene.gltf")
+    depth = False
+    if case.startswith("c3"):
+        scene = scenes.displaced_sphere()
+        if case == "c3_greater":
+            for d in scene.draws:
+                d.depth_compare = scenes.CMP_GREATER
+            scene.clear_depth = 0.0
+        elif case == "c3_two_states":
+            second = copy.copy(scene.draws[0])
+            second.object = scenes.object_ubo(scenes.trs((0.8, 0.8, 0.8), scenes.quat_axis_angle((0.0, 1.0, 0.0), 2.0), (0.3, 0.1, 0.2)))
+            second.depth_compare = scenes.CMP_LESS_OR_EQUAL
+            scene.draws.append(second)
+        depth = True
+    elif case in ("dancer", "dancer_xcd_bins"):
+        scene, depth = scenes.gltf_model(dancer), True
+    elif case in ("dancer_tex", "dancer_tex_xcd_bins"):
+        scene, depth = scenes.gltf_model(dancer, program=scenes.PROGRAM_MODEL_PBR, textures=True), True
+    elif case == "heap_xcd_bins":                        # 20,000 lit triangles heaped into a 2x2-tile corner: every per-XCD list overflows into the big list
+        rng = np.random.default_rng(77)
+        nt = 20000
+        c = rng.uniform(0.005, 0.045, (nt, 1, 2))
+        p = c + rng.normal(0, 0.006, (nt, 3, 2))
+        z = rng.uniform(0.1, 0.9, (nt, 3, 1))
+        pos = np.concatenate([p, z], axis=2).reshape(nt * 3, 3)
+        nrm = rng.normal(0, 1, (nt * 3, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        verts = scenes._pack_vertex48(pos, nrm, rng.uniform(0, 1, (nt * 3, 2)), np.tile(np.float32([1, 0, 0, 1]), (nt * 3, 1)))
+        eye4 = np.eye(4, dtype=np.float32)
+        d0 = scenes.DrawSpec(vertices=verts, stride=48, count=nt * 3, indices=np.arange(nt * 3, dtype=np.uint32),
+                             program=scenes.PROGRAM_MODEL_FULL, cull_mode=scenes.CULL_NONE,
+                             camera=scenes.camera_ubo(eye4, eye4, (0.0, 0.0, 3.0)), object=scenes.object_ubo(eye4),
+                             light=scenes.light_ubo(direction=(0.3, -1.0, 0.2), intensity=1.5, num_point=1),
+                             material=scenes.material_ubo((0.8, 0.6, 0.4, 1.0), 0.0, 0.4, 1.0),
+                             point_lights=scenes.point_light((0.5, 0.5, 2.0), 10.0, (1.0, 1.0, 1.0), 3.0),
+                             albedo_map=scenes.WHITE_1X1, normal_map=scenes.WHITE_1X1)
+        scene, depth = scenes.Scene("mesh-heap", 1920, 1080, [d0], clear_color=(0.1, 0.1, 0.15, 1.0)), True
+    elif case == "depth_image":
+        scene, depth = scenes.displaced_sphere(64, 47, 640, 360, seed=9), True
+    else:
+        scene = scenes.SMALL_CASES[case]()
+        depth = any(d.depth_test for d in scene.draws)
+    out, ref = _render_both(mirhi, oracle, device, scene, want_depth=depth)
+    _check(out, ref, f"{scene.name}-wide{waves}-{case}", depth=depth)
+
+
+def test_wide_variant_is_chosen_from_the_busy_tile_count(mirhi, oracle, scenes):
+    """The host's own choice: a mesh in a part of the frame reports few busy tiles, the plan is rebuilt with the wide variant after the
+    feedback has arrived (and stays the oracle's frame through the switch); a mesh that covers the frame keeps four waves per tile."""
+    dev = mirhi.Device(0)
+    for scene, expect_wide in ((scenes.displaced_sphere(), True), (scenes.heightfield_grid(300, 200, 1920, 1080), False)):
+        res = mirhi.SceneResources(dev, scene, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+        ref = oracle.render(scene, want_bgra8=False)
+        f = mirhi.Fence(dev)
+        for it in range(5):
+            res.render(f); f.wait(); f.reset()
+            assert np.array_equal(res.read()["prim"], ref["prim"]), f"{scene.name}: frame {it}"
+        dev.reset_kernel_times(); dev.set_profiling(mirhi.Profile.TIMING)
+        res.render(f); f.wait(); f.reset()
+        ms, n = dev.kernel_time(mirhi.Kernel.NAMES.index("raster"))
+        dev.set_profiling(0)
+        print(f"{scene.name}: raster {1e3 * ms / max(1, n):.1f} us with the host's choice (wide expected: {expect_wide})")
+        res.destroy(); f.destroy()
+    dev.destroy()

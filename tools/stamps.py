@@ -13,18 +13,23 @@ dev = m.Device(0)
 res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
 for _ in range(3):
     res.render(); dev.wait_idle()
+L.mirhi_debug_clear_stamps()
+res.render(); dev.wait_idle()
 dev.wait_idle()
 def grab(kernel_waves):
-    buf = np.zeros(16384 * 8, dtype=np.uint64)
+    buf = np.zeros(32768 * 8, dtype=np.uint64)
     L.mirhi_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
     return buf.reshape(-1, 8)
 # the stamp buffer is shared by both kernels: raster runs last, so it holds raster stamps for wave ids < raster waves
 st = grab(0).astype(np.int64)
-nw = min(16384, ((scene.width + 31) // 32) * ((scene.height + 31) // 32) * 4)
+wpt = 16 if os.environ.get("MIRHI_RASTER_WIDE") == "1" else 4
+nw = min(32768, ((scene.width + 31) // 32) * ((scene.height + 31) // 32) * wpt)
 s = st[:nw]
 ok = s[:, 4] > 0
 s = s[ok]
 t0 = s[:, 0].min()
+busy = s[(s[:, 4] - s[:, 0]) > 2400 * 3]          # waves that lived longer than 3 us: busy tiles
+print(f"busy waves {len(busy)}: first start -> last end of busy waves {((busy[:,4].max() - busy[:,0].min()) / 2400.0) if len(busy) else 0:.2f} us; start spread of busy waves p50 {np.median(busy[:,0] - t0) / 2400.0 if len(busy) else 0:.2f} max {((busy[:,0] - t0).max() / 2400.0) if len(busy) else 0:.2f} us")
 def us(c): return c / 2400.0   # s_memtime ticks = shader cycles (~2.4 GHz)
 print(f"raster waves {len(s)}: kernel span {us(s[:,4].max() - t0):.2f} us (first start -> last end)")
 for name, a, b in (("prologue (counters)", 0, 1), ("bin list (fill+raster)", 1, 2), ("  of which fill of first chunk", 1, 5), ("big list", 2, 3), ("resolve", 3, 4), ("whole wave", 0, 4)):
