@@ -1241,7 +1241,7 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool sprea
     if (m.wide_eligible) {
         const uint32_t forced = getenv("MIRHI_RASTER_WIDE") ? (uint32_t)atoi(getenv("MIRHI_RASTER_WIDE")) : 0xFFFFFFFFu;
         m.wide = forced == 0xFFFFFFFFu ? wide : (forced == 0u ? 0u : (forced == 8u ? 8u : 16u));
-        if (m.wide) m.teams = 1u;
+        // (teams stays what the scope gets when a submit decides against the wide variant: see mirhi_queue_submit, "frames in flight")
     }
     return m;
 }
@@ -1872,6 +1872,13 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
         if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
+        // Frames in flight, this one included (command buffers submitted and not yet known to have finished).  The wide mesh variants trade
+        // throughput for latency -- a frame alone on the chip finishes sooner (C3 raster 32 -> 25 us), four frames in flight leave each
+        // other less room (C3 16.2 -> 19.8 us per frame) -- so a submit takes them only while the queue is shallow: the reference's
+        // MAX_FRAMES_IN_FLIGHT = 2 loop does, a loop that keeps four frames queued gets the plain / two-team variants.
+        int in_flight = 1;
+        for (const mirhi_cmd* o : dev->cmds) in_flight += (o != c && o->pending) ? 1 : 0;
+        const bool allow_wide = in_flight <= 2 || getenv("MIRHI_RASTER_WIDE") != nullptr;
         c->last_stream = stream; c->pending = true; c->submit_seq++;
         { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
@@ -1921,7 +1928,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             if (timed && has_tiles) { mirhi_result r = timing_begin(dev, MIRHI_KERNEL_RASTER, c->lane, &tr); if (r != MIRHI_OK) return r; }
             if (fence_stop && i + 1 == cmd_count && pi + 1 == c->plan.size() && has_tiles) { tr.stop = fence_stop; fence_attached = true; }   // (never together with `timed`)
             if (!keep_locked) lock.unlock();
-            le = launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr);
+            le = launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr, allow_wide);
             if (!keep_locked) lock.lock();
             HIP_TRY(le);
             if (winners) HIP_TRY(launch_winner_count(winners, P.width * P.height, dev->frag_stats, stream));

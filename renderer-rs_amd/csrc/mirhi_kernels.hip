@@ -85,7 +85,7 @@ static void launch_raster_k(const PassParams* P, const RasterHead& H, uint32_t p
     else MIRHI_LAUNCH((raster_kernel<1, KEYED, TP>), grid, block, stream, t, P, H);
 }
 
-hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t) {
+hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t, bool allow_wide) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
     if (P.ordered_recs) {           // ordered segment: fragments in primitive order (blending)
@@ -101,7 +101,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
     const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
-    if (P.raster_wide && !P.pred && P.tp_max_area && P.raster_teams != 2u && !P.alpha_scope && (programs == 2 || programs >= 4) && P.xcd_swizzle <= 1u) {
+    if (P.raster_wide && allow_wide && !P.pred && P.tp_max_area && !P.alpha_scope && (programs == 2 || programs >= 4) && P.xcd_swizzle <= 1u) {
         // the wide mesh variants: eight or sixteen waves per tile (host-side choice, PassParams::raster_wide = waves per tile)
         const bool w16 = P.raster_wide >= 16u;
         const dim3 wb(w16 ? 1024 : 512);

@@ -15,7 +15,8 @@ hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipS
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
 // programs: bit0 TRIANGLE, bit1 MODEL / MODEL_FULL, bit2 MODEL_PBR
-hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t = {});
+// allow_wide: false = the scope's plain / two-team variant even if its plan names a wide one (PassParams::raster_wide): the submit's choice
+hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, uint32_t programs, hipStream_t stream, LaunchTiming t = {}, bool allow_wide = true);
 // Batched forms: n (2 .. MAX_BATCH) independent scopes of equal target shape and equal kernel variants (raster_variant_key) in one
 // launch each; P[i] / dev_params[i] / big_count[i] as above, per scope.  Ordered (blended) scopes are never batched.
 bool raster_batchable(const PassParams& P);                                 // a variant that exists in batched form

@@ -47,25 +47,26 @@ __device__ __forceinline__ uint32_t clamp_box(int32_t bx0, int32_t bx1, int32_t 
     return (uint32_t)bx0 | (((uint32_t)bx1 & 0xFFu) << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
 }
 
-// (opx, opy): the tile's origin in the pixel frame T.X / T.Y are given in -- (0, 0) for a bin record, which is relative to its
-// tile; the tile's position in the target for a big-list record, whose coordinates are absolute.  Wave-uniform.
-__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
-    const int32_t Ptx = 256 * opx + 128, Pty = 256 * opy + 128;           // tile origin pixel centre, 1/256 px
+// The arithmetic of a tile record, ONE copy for both record sources (bin records relative to their tile, big-list / ordered records in
+// absolute screen coordinates): X / Y the snapped vertices and (Ptx, Pty) the tile origin's pixel centre in the same 1/256-pixel frame,
+// (bx0..by1) the inclusive pixel box relative to the tile (already clamped; lo > hi: it misses the tile), (fox, foy) the tile origin in
+// pixels of that frame.  Forced inline: every caller keeps its own register allocation (the TRIANGLE-only variants live on 64 VGPRs).
+__device__ __forceinline__ bool tile_rec_core(uint4 out[4], const int32_t X[3], const int32_t Y[3], int32_t Ptx, int32_t Pty,
+                                              int32_t bx0, int32_t bx1, int32_t by0, int32_t by1, float fox, float foy,
+                                              uint32_t z0, uint32_t zx, uint32_t zy, uint32_t idk, uint32_t boxed) {
     int32_t A[3], B[3], Q[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int a = i, b = (i + 1) % 3;
-        const int32_t dx = T.X[b] - T.X[a], dy = T.Y[b] - T.Y[a];
+        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
         A[i] = -dy; B[i] = dx;
         const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
         // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22 and |tile origin| < 2^21 in absolute terms)
-        const int64_t e0 = mul24x24(A[i], Ptx - T.X[a]) + mul24x24(B[i], Pty - T.Y[a]) + (topleft ? 0 : -1);
+        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
         int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
         q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
         Q[i] = (int32_t)q;
     }
-    const int32_t bx0 = (int32_t)(T.box & 0xFFu), bx1 = (int32_t)(int8_t)((T.box >> 8) & 0xFFu);
-    const int32_t by0 = (int32_t)((T.box >> 16) & 0xFFu), by1 = (int32_t)T.box >> 24;
     // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
     // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
     // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
@@ -94,14 +95,22 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
     const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
     const float inv256 = 1.0f / 256.0f;
-    const float dxt = ((float)opx + 0.5f) - (float)T.X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
-    const float dyt = ((float)opy + 0.5f) - (float)T.Y[0] * inv256;
+    const float dxt = (fox + 0.5f) - (float)X[0] * inv256;                  // exact: multiples of 2^-8 below 2^15
+    const float dyt = (foy + 0.5f) - (float)Y[0] * inv256;
     out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
     out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
-    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), T.z0);
-    out[3] = make_uint4(T.zx, T.zy, T.idk, mask | T.boxed);
-    box = T.box;
+    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), z0);
+    out[3] = make_uint4(zx, zy, idk, mask | boxed);
     return mask != 0;
+}
+
+// (opx, opy): the tile's origin in the pixel frame T.X / T.Y are given in -- (0, 0) for a bin record, which is relative to its
+// tile; the tile's position in the target for a big-list record, whose coordinates are absolute.  Wave-uniform.
+__device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const TileTri& T, int32_t opx = 0, int32_t opy = 0) {
+    const int32_t bx0 = (int32_t)(T.box & 0xFFu), bx1 = (int32_t)(int8_t)((T.box >> 8) & 0xFFu);
+    const int32_t by0 = (int32_t)((T.box >> 16) & 0xFFu), by1 = (int32_t)T.box >> 24;
+    box = T.box;
+    return tile_rec_core(out, T.X, T.Y, 256 * opx + 128, 256 * opy + 128, bx0, bx1, by0, by1, (float)opx, (float)opy, T.z0, T.zx, T.zy, T.idk, T.boxed);
 }
 
 // BinRec (already relative to its tile) -> TileTri; the pixel box is recomputed from the vertices (no scissor cuts a binned triangle)
@@ -128,70 +137,17 @@ __device__ __forceinline__ bool tile_tri_from_big(TileTri& T, const uint4 w0, co
     return true;
 }
 // TriRec (absolute screen coordinates: big list, ordered segments) -> tile record for tile (tx, ty); false if no 8x8 block of the
-// tile can be touched.  Same arithmetic as the TileTri form above with the tile's origin added back (its own copy: fed from one
-// body, the two record forms cost the TRIANGLE-only variants, which live on 64 VGPRs, a dozen spills).
-//   w0 = { Q0, Q1, Q2, A0 }   Q_i = floor((E_i(tile origin pixel centre) + bias_i) / 256), clamped to +-2^30
-//   w1 = { A1, A2, B0, B1 }   A_i = Ya - Yb, B_i = Xb - Xa in 1/256 px (|.| < 2^23, fits v_mad_i32_i24)
-//   w2 = { B2, dxt, dyt, z0 } (tile origin pixel centre) - (snapped vertex 0), in pixels (exact), vertex-0 depth
-//   w3 = { zx, zy, idk, mask } mask bits 0..15 = 8x8 blocks the triangle may touch, bit 31 = pixel box applies
+// tile can be touched.  The same arithmetic (tile_rec_core) with the tile's origin added back.
 __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const uint4 w0, const uint4 w1, const uint4 w2,
                                               int32_t tx, int32_t ty) {
     const int32_t X[3] = {(int32_t)w0.x, (int32_t)w0.z, (int32_t)w1.x}, Y[3] = {(int32_t)w0.y, (int32_t)w0.w, (int32_t)w1.y};
     const int32_t ox = tx * TILE, oy = ty * TILE;
-    const int32_t Ptx = 256 * ox + 128, Pty = 256 * oy + 128;           // tile origin pixel centre, 1/256 px
-    int32_t A[3], B[3], Q[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int a = i, b = (i + 1) % 3;
-        const int32_t dx = X[b] - X[a], dy = Y[b] - Y[a];
-        A[i] = -dy; B[i] = dx;
-        const bool topleft = (dy < 0) || (dy == 0 && dx > 0);              // top-left fill rule
-        // E_i + bias at the tile origin; every factor fits 24 bits (|X|,|Y| < 2^22, |Pt| < 2^21)
-        const int64_t e0 = mul24x24(A[i], Ptx - X[a]) + mul24x24(B[i], Pty - Y[a]) + (topleft ? 0 : -1);
-        int64_t q = e0 >> 8;                                 // floor(E/256): E = 256*(q + A*ix + B*iy) + r, 0 <= r < 256
-        q = q > (1 << 30) ? (1 << 30) : (q < -(1 << 30) ? -(1 << 30) : q);
-        Q[i] = (int32_t)q;
-    }
     int32_t bx0 = (int32_t)(w2.z & 0x7FFFu) - ox, bx1 = (int32_t)((w2.z >> 16) & 0x7FFFu) - ox;
     int32_t by0 = (int32_t)(w2.w & 0xFFFFu) - oy, by1 = (int32_t)(w2.w >> 16) - oy;
     bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
     bx1 = bx1 > TILE - 1 ? TILE - 1 : bx1; by1 = by1 > TILE - 1 ? TILE - 1 : by1;
-    // conservative 8x8 block mask: a block is dropped if it misses the pixel box or lies outside one edge.
-    // Per edge the value at the most-inside pixel of block (bx,by) is c_i + 8*(A_i*bx + B_i*by).  Straight-line code:
-    // three adds, one OR of the three edge values and one funnel shift that appends the sign bit (set = outside) per
-    // block -- no compares, no branches, nothing on the scalar unit.
-    int32_t c[3], a8[3], b8[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        c[i] = Q[i] + (A[i] >= 0 ? A[i] * (BLOCK - 1) : 0) + (B[i] >= 0 ? B[i] * (BLOCK - 1) : 0);
-        a8[i] = A[i] * BLOCK; b8[i] = B[i] * BLOCK;
-    }
-    uint32_t outside = 0;                               // after the loop: bit (15 - (by*4+bx)) set <=> block outside an edge
-#pragma unroll
-    for (int by = 0; by < 4; by++) {
-        int32_t v0 = c[0], v1 = c[1], v2 = c[2];
-#pragma unroll
-        for (int bx = 0; bx < 4; bx++) {
-            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)(v0 | v1 | v2), 31);   // (outside << 1) | sign
-            v0 += a8[0]; v1 += a8[1]; v2 += a8[2];
-        }
-        c[0] += b8[0]; c[1] += b8[1]; c[2] += b8[2];
-    }
-    // pixel box -> block box -> mask of the blocks inside it (4 column bits replicated per row, row bits spread to nibbles)
-    const uint32_t cols = ((2u << ((uint32_t)bx1 >> 3)) - 1u) & ~((1u << ((uint32_t)bx0 >> 3)) - 1u);          // bits bx0b..bx1b
-    const uint32_t rows = ((2u << ((uint32_t)by1 >> 3)) - 1u) & ~((1u << ((uint32_t)by0 >> 3)) - 1u);
-    const uint32_t rowsel = ((rows & 1u) * 0xFu) | ((rows & 2u) * 0x78u) | ((rows & 4u) * 0x3C0u) | ((rows & 8u) * 0x1E00u);
-    const uint32_t inside = __builtin_bitreverse32(~outside) >> 16;         // bit (by*4+bx) set <=> not outside any edge
-    const uint32_t mask = (bx0 <= bx1 && by0 <= by1) ? (inside & (cols * 0x1111u) & rowsel) : 0u;
-    const float inv256 = 1.0f / 256.0f;
-    const float dxt = ((float)ox + 0.5f) - (float)X[0] * inv256;         // exact: multiples of 2^-8 below 2^15
-    const float dyt = ((float)oy + 0.5f) - (float)Y[0] * inv256;
-    out[0] = make_uint4((uint32_t)Q[0], (uint32_t)Q[1], (uint32_t)Q[2], (uint32_t)A[0]);
-    out[1] = make_uint4((uint32_t)A[1], (uint32_t)A[2], (uint32_t)B[0], (uint32_t)B[1]);
-    out[2] = make_uint4((uint32_t)B[2], __float_as_uint(dxt), __float_as_uint(dyt), w1.z);
-    out[3] = make_uint4(w1.w, w2.x, w2.y, mask | (w2.z & 0x80000000u));
     box = (uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24);
-    return mask != 0;
+    return tile_rec_core(out, X, Y, 256 * ox + 128, 256 * oy + 128, bx0, bx1, by0, by1, (float)ox, (float)oy, w1.z, w1.w, w2.x, w2.y, w2.z & 0x80000000u);
 }
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
