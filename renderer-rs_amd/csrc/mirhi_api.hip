@@ -1474,7 +1474,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         size_t off = 0; uint32_t slots = 0;
         for (size_t di = 0; di < pass.draws.size(); di++) {
             DrawDesc& dd = pass_draws[pi][di];
-            dd.vs_words = 0; dd.vs_out = nullptr;
+            dd.vs_words = 0; dd.vs_out = nullptr; dd.vs_attr = nullptr;
             if (dd.program == MIRHI_PROGRAM_TRIANGLE) continue;
             const uint32_t words = dd.program == MIRHI_PROGRAM_MODEL ? 3u : 5u;
             const uint64_t vbb = pass.draw_vb_bytes[di];
@@ -1489,12 +1489,13 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
                 hj.j.vb = dd.vb; hj.j.camera = dd.camera; hj.j.object = dd.object; hj.j.stride = dd.stride; hj.j.count = count;
                 hj.j.words = words; hj.j.slot_base = slots; hj.out_off = off;
                 slots += (count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS;
-                off += ((size_t)count * words * 16 + 255) & ~(size_t)255;
+                off += vs_attr_offset(count) + (((size_t)count * (words - 1u) * 16 + 255) & ~(size_t)255);      // clip stream, then the attribute stream
                 pass_jobs[pi].push_back(hj);
                 found = pass_jobs[pi].size() - 1;
             }
             dd.vs_words = pass_jobs[pi][found].j.words;
             dd.vs_out = (const void*)(uintptr_t)(pass_jobs[pi][found].out_off + 1);   // offset + 1, patched to a pointer below
+            dd.vs_attr = (const void*)(uintptr_t)(pass_jobs[pi][found].out_off + vs_attr_offset(pass_jobs[pi][found].j.count) + 1);
         }
         if (off > vs_bytes_max) vs_bytes_max = off;
         jobs_total += pass_jobs[pi].size();
@@ -1618,7 +1619,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         }
         jobs_done += pass_jobs[pi].size();
         for (DrawDesc& dd : draws)
-            if (dd.vs_words) dd.vs_out = w.vs_out + ((size_t)(uintptr_t)dd.vs_out - 1);
+            if (dd.vs_words) { dd.vs_out = w.vs_out + ((size_t)(uintptr_t)dd.vs_out - 1); dd.vs_attr = w.vs_out + ((size_t)(uintptr_t)dd.vs_attr - 1); }
         uint32_t slots = 0;
         for (DrawDesc& dd : draws) { dd.slot_base = slots; slots += (dd.tri_count + GEOM_THREADS - 1) / GEOM_THREADS * GEOM_THREADS; }
         P.total_slots = slots;

@@ -68,16 +68,19 @@ struct DrawDesc {
     uint32_t scissor_partial;     // scissor smaller than the target: per-pixel box test needed when it cuts a bbox
     uint32_t vs_words;            // 16-byte words per shaded vertex (3 MODEL, 5 MODEL_FULL, 0 = no vertex pre-pass)
     uint32_t tex_aniso;           // bits 4t..4t+3: max_anisotropy - 1 of texture t (0 = trilinear; set only for textures with a chain)
-    uint32_t pad[2];
-    const void* vs_out;           // shaded vertices of this draw's vertex buffer (see VsJob), indexed like the vertex buffer
+    const void* vs_attr;          // shaded vertices, the other words (vs_words - 1 per vertex): see VsJob
+    const void* vs_out;           // shaded vertices, clip positions (16 B per vertex), indexed like the vertex buffer: see VsJob
 };
 static_assert(sizeof(DrawDesc) % 16 == 0, "DrawDesc must stay 16-byte sized");
 
 // Vertex-shader pre-pass (vertex/model.hlsl:39-68 run once per vertex, as a GPU's vertex stage does, instead of three
 // times per shaded pixel): one job per distinct (vertex buffer range, camera, object, program class) of a scope.
-// Shaded vertex = vs_words 16-byte words:
-//   w0 = clip position            w1 = { world.xyz, N.x }        w2 = { N.y, N.z, u, v }
-//   MODEL_FULL adds               w3 = { T.xyz, B.x }            w4 = { B.y, B.z, 0, 0 }
+// Shaded vertex = vs_words 16-byte words in TWO streams: the clip position on its own (what the geometry kernel gathers for every
+// triangle of every rank: 16 B per vertex, not a 48 / 80-byte row -- C4: 8 MB instead of 24 MB per frame and rank), the rest behind it
+//   clip[v]  = clip position
+//   attr[v]  = { world.xyz, N.x }, { N.y, N.z, u, v }                     (vs_words - 1 = 2 words, MODEL)
+//              + { T.xyz, B.x }, { B.y, B.z, 0, 0 }                       (vs_words - 1 = 4 words, MODEL_FULL / MODEL_PBR)
+// A job's output is [count x 16 B clip, rounded up to 256 B][count x (words - 1) x 16 B]: vs_attr_of() below.
 struct VsJob {
     const uint8_t* vb;
     const float*   camera;
@@ -86,6 +89,11 @@ struct VsJob {
     uint32_t stride, count, slot_base, words;
 };
 static_assert(sizeof(VsJob) == 48, "VsJob is 48 bytes");
+// the attribute stream of a job's output block `out` for `count` vertices (host and device agree through this one function)
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline size_t vs_attr_offset(uint32_t count) { return ((size_t)count * 16u + 255u) & ~(size_t)255u; }
 
 // Screen-space triangle record, 12 dwords = three 16-byte words.  Written once per overlapped tile into
 // that tile's bin (and once into the big list for triangles that span more than 4x4 tiles, were clipped,

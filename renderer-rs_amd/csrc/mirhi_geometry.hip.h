@@ -233,8 +233,9 @@ __device__ __forceinline__ void vertex_body(const PassParams* __restrict__ param
     const f4 c = mat4_mul(cf(J.camera) + 32, w);                             // :48
     const f3 n = {ldf(v, 12), ldf(v, 16), ldf(v, 20)};
     const f3 N = normalize3(mat3_mul(model + 16, n));                        // :51
-    uint4* out = reinterpret_cast<uint4*>(J.out) + (size_t)vidx * J.words;
-    out[0] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
+    reinterpret_cast<uint4*>(J.out)[vidx] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), __float_as_uint(c.w));
+    // (out[1..]: the attribute stream behind the clip positions, words - 1 per vertex)
+    uint4* out = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(J.out) + vs_attr_offset(J.count)) + (size_t)vidx * (J.words - 1u) - 1;
     out[1] = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(N.x));
     out[2] = make_uint4(__float_as_uint(N.y), __float_as_uint(N.z), ldu(v, 24), ldu(v, 28));
     if (J.words == 5) {
@@ -535,7 +536,7 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t vidx = fetch_index(D, 3u * tri + k);
             if (D.vs_words) {                      // MODEL programs: clip position from the vertex pre-pass
-                const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[(size_t)vidx * D.vs_words];
+                const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[vidx];
                 c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
             } else {
                 c[k] = vs_position(D, vidx, nullptr);

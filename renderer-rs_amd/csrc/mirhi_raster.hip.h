@@ -251,8 +251,8 @@ __device__ __forceinline__ void raster_record_masked(const RecRegs& r, int32_t i
     f4 c[3]; float uvk[3][2];
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vin[k] * D.vs_words;
-        const uint4 w0 = sv[0], w2 = sv[2];
+        const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[vin[k]];
+        const uint4 w2 = (reinterpret_cast<const uint4*>(D.vs_attr) + (size_t)vin[k] * (D.vs_words - 1u))[1];
         c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
         uvk[k][0] = __uint_as_float(w2.z); uvk[k][1] = __uint_as_float(w2.w);
     }
@@ -384,8 +384,8 @@ __device__ __forceinline__ void raster_small_masked(DrawRef D, uint32_t prim, co
     f4 c[3]; float uvk[3][2];
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vin[k] * D.vs_words;
-        const uint4 w0 = sv[0], w2 = sv[2];
+        const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[vin[k]];
+        const uint4 w2 = (reinterpret_cast<const uint4*>(D.vs_attr) + (size_t)vin[k] * (D.vs_words - 1u))[1];
         c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
         uvk[k][0] = __uint_as_float(w2.z); uvk[k][1] = __uint_as_float(w2.w);
     }

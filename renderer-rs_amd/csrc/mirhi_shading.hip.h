@@ -150,7 +150,7 @@ __device__ __forceinline__ void interp_tangent_frame(DrawRef D, const uint32_t v
     T = {0.0f, 0.0f, 0.0f}; Bt = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words;
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_attr) + (size_t)vi[k] * (D.vs_words - 1u) - 1;     // (sv[1..]: the attribute words)
         const uint4 w3 = sv[3], w4 = sv[4];
         acc3(T, b[k], {__uint_as_float(w3.x), __uint_as_float(w3.y), __uint_as_float(w3.z)}, k);
         acc3(Bt, b[k], {__uint_as_float(w3.w), __uint_as_float(w4.x), __uint_as_float(w4.y)}, k);
@@ -373,7 +373,7 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, const uint32_t vi[3
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
         // vertex/model.hlsl outputs, computed once per vertex by vertex_kernel: the clip position first
-        const uint4 w0 = (reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words)[0];
+        const uint4 w0 = reinterpret_cast<const uint4*>(D.vs_out)[vi[k]];
         c[k] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)};
     }
     float b[3];
@@ -382,7 +382,7 @@ __device__ __forceinline__ f4 shade_model_program(DrawRef D, const uint32_t vi[3
     float u = 0.0f, v = 0.0f, uvk[3][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
     for (uint32_t k = 0; k < 3; k++) {
-        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_out) + (size_t)vi[k] * D.vs_words;
+        const uint4* sv = reinterpret_cast<const uint4*>(D.vs_attr) + (size_t)vi[k] * (D.vs_words - 1u) - 1;     // (sv[1..]: the attribute words)
         const uint4 w1 = sv[1], w2 = sv[2];
         acc3(worldPos, b[k], {__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z)}, k);
         acc3(Nv, b[k], {__uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y)}, k);
