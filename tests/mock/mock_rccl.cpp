@@ -21,6 +21,7 @@ std::deque<Op> g_pending;
 std::vector<Op> g_group;
 int g_depth = 0;
 size_t g_matched = 0, g_bytes = 0;
+int g_fail_send_in = 0;          // test hook: the n-th ncclSend from now fails (0 = none)
 
 size_t type_size(ncclDataType_t t) { return (t == ncclInt8 || t == ncclUint8) ? 1 : (t == ncclFloat16 || t == ncclBfloat16) ? 2 : (t == ncclFloat64 || t == ncclInt64 || t == ncclUint64) ? 8 : 4; }
 
@@ -82,6 +83,7 @@ ncclResult_t ncclGroupEnd() {
 }
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
     if (peer < 0 || peer >= comm->world || peer == comm->rank) return ncclInvalidArgument;
+    { std::lock_guard<std::mutex> lock(g_mu); if (g_fail_send_in > 0 && --g_fail_send_in == 0) return ncclSystemError; }
     return post(Op{true, comm->rank, peer, const_cast<void*>(buf), count * type_size(type), stream});
 }
 ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t comm, hipStream_t stream) {
@@ -100,4 +102,8 @@ const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no e
 size_t mock_rccl_pending() { std::lock_guard<std::mutex> lock(g_mu); return g_pending.size() + g_group.size(); }
 size_t mock_rccl_matched() { std::lock_guard<std::mutex> lock(g_mu); return g_matched; }
 size_t mock_rccl_bytes() { std::lock_guard<std::mutex> lock(g_mu); return g_bytes; }
+// the n-th ncclSend from now returns ncclSystemError; the thread's group depth (must be 0 again after a failed exchange); forget everything posted
+void mock_rccl_fail_send_in(int n) { std::lock_guard<std::mutex> lock(g_mu); g_fail_send_in = n; }
+int mock_rccl_group_depth() { std::lock_guard<std::mutex> lock(g_mu); return g_depth; }
+void mock_rccl_reset() { std::lock_guard<std::mutex> lock(g_mu); g_pending.clear(); g_group.clear(); g_fail_send_in = 0; }
 }

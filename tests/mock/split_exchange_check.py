@@ -65,4 +65,40 @@ for (W, H, N, algo_name) in CASES:
     for r in range(N):
         ress[r].destroy(); devs[r].destroy()
     print(f"{W}x{H} ranks {N} {algo_name}: {'ok' if ok else 'FAILED'} ({moved} bytes exchanged)", flush=True)
+# A failing ncclSend inside the grouped exchange (ADVICE r2 / VERDICT r2 item 6b): the call reports it, the thread's RCCL group is closed
+# again (an open group would swallow every later RCCL call of the thread), and the next exchange works.
+mock.mock_rccl_group_depth.restype = ctypes.c_int
+scene = m.scenes.random_triangles(300, 320, 200, seed=77, rmin=3, rmax=40)
+solo = m.Device(0)
+res0 = m.SceneResources(solo, scene, m.Format.B8G8R8A8_SRGB); res0.render(); ref = res0.read()["color"].copy(); res0.destroy(); solo.destroy()
+N = 3
+devs = [m.Device(0) for _ in range(N)]
+uid = m.Comm.unique_id()
+comms = [m.Comm(devs[r], uid, r, N) for r in range(N)]
+ress = [m.SceneResources(devs[r], scene, m.Format.B8G8R8A8_SRGB) for r in range(N)]
+for r in range(N):
+    ress[r].render()
+mock.mock_rccl_fail_send_in(2)                       # rank 0's second send
+raised = False
+try:
+    comms[0].all_gather_bands(ress[0].color, ress[0].cmd, m.GatherAlgo.DIRECT)
+except m.RhiError as e:
+    raised = "RCCL" in str(e)
+ok = raised and mock.mock_rccl_group_depth() == 0
+mock.mock_rccl_reset()
+for r in range(N):
+    devs[r].wait_idle()
+for r in range(N):
+    ress[r].render()
+for r in range(N):
+    comms[r].all_gather_bands(ress[r].color, ress[r].cmd, m.GatherAlgo.DIRECT)
+for r in range(N):
+    devs[r].wait_idle()
+ok = ok and mock.mock_rccl_pending() == 0 and all(np.array_equal(ress[r].read()["color"], ref) for r in range(N))
+for c in comms:
+    c.destroy()
+for r in range(N):
+    ress[r].destroy(); devs[r].destroy()
+print(f"failing send inside the group: {'ok' if ok else 'FAILED'} (error reported: {raised}, group depth afterwards {mock.mock_rccl_group_depth()})", flush=True)
+failures += 0 if ok else 1
 sys.exit(1 if failures else 0)

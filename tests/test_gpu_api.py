@@ -916,4 +916,4 @@ def test_band_exchange_with_n_ranks_on_one_gpu(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "mock", "split_exchange_check.py"), lib], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
-    assert p.stdout.count(": ok") == 7, p.stdout[-3000:]
+    assert p.stdout.count(": ok") == 8, p.stdout[-3000:]       # 7 exchanges + the failing-send case (the group is closed again, the next exchange works)

@@ -1,20 +1,52 @@
-"""Per-kernel times of one rank's share of a tile-row split (emulated on one GPU). usage: split_times.py [workload] [world]"""
-import os, sys
+"""Per-rank kernel times of a screen-tile-row split, EMULATED ON ONE GPU: every rank of world 2 / 4 / 8 renders its band in turn (isolated
+dispatches, event pair on each), and the 1 -> N curve is PREDICTED from them: a frame's time on N GPUs = the slowest rank's kernels, or the
+band exchange if that is longer (direct sends over a full xGMI mesh: every link carries one band, frame_bytes / N at 153 GB/s; the exchange
+of frame f overlaps the kernels of frame f + 1 with two frames in flight).  Nothing here has run on more than one GPU.
+usage: split_times.py [--json out.json] [workloads...]      (default: c4 c5)"""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 m = ge.load_package()
-wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
-world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-scene = {"c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid, "c5": m.scenes.box_hall}[wl]()
-for rank in (None, 0, world // 2, world - 1):
-    dev = m.Device(0)
-    if rank is not None: dev.set_tile_split(rank, world)
-    res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
-    for _ in range(10): res.render()
-    dev.wait_idle()
-    dev.set_profiling(True); dev.reset_kernel_times()
-    for _ in range(100): res.render()
-    dev.wait_idle()
-    g, gn = dev.kernel_time(m.Kernel.GEOMETRY); r, rn = dev.kernel_time(m.Kernel.RASTER)
-    print(f"{wl} rank {rank} of {world}: geometry {1e3 * g / max(gn, 1):7.2f} us  raster {1e3 * r / max(rn, 1):7.2f} us")
-    res.destroy(); dev.destroy()
+args = sys.argv[1:]
+out_path = None
+if "--json" in args:
+    i = args.index("--json"); out_path = args[i + 1]; del args[i:i + 2]
+LINK_GBS = 153.0
+result = {"note": "emulated on one MI355X: per-rank kernel times are measured (isolated dispatches), the curve is predicted from them", "link_GB_per_s": LINK_GBS, "workloads": {}}
+for wl in args or ["c4", "c5"]:
+    scene = {"c2": m.scenes.random_triangles, "c3": m.scenes.displaced_sphere, "c4": m.scenes.heightfield_grid, "c5": m.scenes.box_hall}[wl]()
+    frame_bytes = scene.width * scene.height * 4
+    table = {}
+
+    def measure(rank, world):
+        dev = m.Device(0)
+        if world > 1:
+            dev.set_tile_split(rank, world)
+        res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
+        for _ in range(6):
+            res.render()
+        dev.wait_idle()
+        dev.set_profiling(m.Profile.TIMING); dev.reset_kernel_times()
+        for _ in range(24):
+            res.render(); dev.wait_idle()
+        t = {name: dev.kernel_time(k) for k, name in enumerate(m.Kernel.NAMES)}
+        res.destroy(); dev.destroy()
+        return {k: round(1e3 * ms / n, 2) if n else 0.0 for k, (ms, n) in t.items() if k != "fragment_count"}
+
+    one = measure(0, 1)
+    t1 = sum(one.values())
+    table["1"] = {"ranks": [one], "frame_us": round(t1, 2), "speedup": 1.0}
+    print(f"{wl} world 1: {one} = {t1:.1f} us", flush=True)
+    for world in (2, 4, 8):
+        ranks = [measure(r, world) for r in range(world)]
+        slow = max(sum(r.values()) for r in ranks)
+        exch = 1e6 * (frame_bytes / world) / (LINK_GBS * 1e9)
+        frame = max(slow, exch)
+        fixed = min(r["geometry"] for r in ranks) / one["geometry"] if one["geometry"] else 0.0
+        table[str(world)] = {"ranks": ranks, "slowest_rank_kernels_us": round(slow, 2), "exchange_us_modelled": round(exch, 2), "frame_us_predicted": round(frame, 2),
+                             "speedup_predicted": round(t1 / frame, 2), "geometry_share_of_cheapest_rank": round(fixed, 3)}
+        print(f"{wl} world {world}: slowest rank {slow:.1f} us (vertex / geometry / raster per rank: " +
+              " | ".join(f"{r['vertex']:.1f}/{r['geometry']:.1f}/{r['raster']:.1f}" for r in ranks) + f"), exchange {exch:.1f} us -> predicted x{t1 / frame:.2f}", flush=True)
+    result["workloads"][wl] = {"triangles": scene.num_triangles, "width": scene.width, "height": scene.height, "worlds": table}
+if out_path:
+    json.dump(result, open(out_path, "w"), indent=1)
