@@ -26,7 +26,7 @@ def hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(HERE, "libmirhi_kernels.hsaco")):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -57,11 +57,32 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-L/opt/rocm/lib", "-lhsa-runtime64"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if out == LIB:
+        extract_code_object(objs[0], HSACO, verbose)
     return out
+
+
+HSACO = os.path.join(HERE, "libmirhi_kernels.hsaco")
+
+
+def extract_code_object(obj: str, dst: str, verbose: bool = False) -> None:
+    """The gfx950 code object of the kernels, as a file beside the library: the native dispatcher (csrc/mirhi_native.h) loads it through
+    ROCr.  Taken out of the object hipcc just produced (its .hip_fatbin section is a clang offload bundle) -- the same bits the HIP
+    runtime loads, no second compilation."""
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib", "llvm", "bin")
+    if not os.path.exists(os.path.join(llvm, "llvm-objcopy")):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    fat = dst + ".bundle"
+    for cmd in ([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj],
+                [os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dst]):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    os.remove(fat)
 
 
 def build_stamps(verbose: bool = False) -> str:

@@ -22,6 +22,8 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <rccl/rccl.h>     // types and prototypes only: librccl is loaded with dlopen on first use (no link-time dependency)
 
 #include "../../include/mirhi.h"
@@ -79,6 +81,192 @@ extern "C" const char* mirhi_result_name(mirhi_result r) {
     }
 }
 
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// ------------------------------------------------------------------------------------------------
+// native dispatch: AQL packets written by this library (mirhi_native.h)
+// ------------------------------------------------------------------------------------------------
+namespace mirhi {
+struct NativeKernel { uint64_t object; uint32_t kernarg_bytes, lds_bytes, scratch_bytes; };
+struct NativeDevice {
+    hsa_agent_t agent{};
+    hsa_executable_t exe{};
+    std::mutex mu;
+    std::vector<std::pair<const void*, NativeKernel>> kernels;      // by host function address (a handful: linear search)
+    bool ok = false;
+    std::string why;
+};
+struct NativeQueue {
+    NativeDevice* nd = nullptr;
+    hsa_queue_t* q = nullptr;
+    uint8_t* ring = nullptr;                 // kernel arguments: fine-grained device memory, host-written
+    size_t ring_bytes = 0, ring_pos = 0;
+    uint64_t widx = 0, drained = 0;          // packets written so far / packets known to have completed
+    hsa_signal_t drain_sig{};
+    std::mutex mu;                           // one producer at a time (a host thread that waits for the queue also writes a packet)
+};
+}  // namespace mirhi
+namespace {
+// code object v5 implicit kernel arguments as far as the kernels need them (blockIdx / gridDim / blockDim)
+struct ImplicitArgs { uint32_t block_count[3]; uint16_t group_size[3]; uint16_t remainder[3]; uint8_t reserved[16]; uint64_t global_offset[3]; uint16_t grid_dims; uint8_t pad[6]; };
+static_assert(sizeof(ImplicitArgs) == 72, "implicit argument block (the part this library fills)");
+constexpr size_t NATIVE_RING_BYTES = 256 * 1024;
+constexpr uint32_t NATIVE_QUEUE_PACKETS = 1024;
+
+hsa_status_t native_pick_agent(hsa_agent_t a, void* data) {
+    auto* want = static_cast<std::pair<uint32_t, hsa_agent_t*>*>(data);      // PCI bus:device.function of the HIP device
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if ((bdf & 0xFFFFu) == (want->first & 0xFFFFu) && want->second->handle == 0) *want->second = a;
+    return HSA_STATUS_SUCCESS;
+}
+
+// the directory this shared library was loaded from (the code object sits beside it)
+std::string native_library_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&native_library_dir), &info) || !info.dli_fname) return ".";
+    std::string p = info.dli_fname;
+    const size_t slash = p.find_last_of('/');
+    return slash == std::string::npos ? "." : p.substr(0, slash);
+}
+
+mirhi::NativeDevice* native_device_open(int ordinal) {
+    auto* nd = new mirhi::NativeDevice();
+    auto fail_with = [&](const std::string& w) { nd->why = w; return nd; };
+    if (getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 0) return fail_with("switched off (MIRHI_NATIVE_DISPATCH=0)");
+    if (hsa_init() != HSA_STATUS_SUCCESS) return fail_with("hsa_init failed");
+    int bus = 0, devid = 0;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, ordinal) != hipSuccess || hipDeviceGetAttribute(&devid, hipDeviceAttributePciDeviceId, ordinal) != hipSuccess) { (void)hipGetLastError(); return fail_with("no PCI id for the HIP device"); }
+    std::pair<uint32_t, hsa_agent_t*> want{(uint32_t)((bus << 8) | (devid << 3)), &nd->agent};
+    (void)hsa_iterate_agents(native_pick_agent, &want);
+    if (nd->agent.handle == 0) return fail_with("no ROCr agent with the HIP device's PCI id");
+    const std::string path = native_library_dir() + "/libmirhi_kernels.hsaco";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return fail_with(path + " is missing (build.py writes it)");
+    std::vector<char> blob;
+    { char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) blob.insert(blob.end(), buf, buf + n); }
+    fclose(f);
+    hsa_code_object_reader_t reader;
+    if (hsa_code_object_reader_create_from_memory(blob.data(), blob.size(), &reader) != HSA_STATUS_SUCCESS) return fail_with("code object reader");
+    if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &nd->exe) != HSA_STATUS_SUCCESS) return fail_with("executable create");
+    if (hsa_executable_load_agent_code_object(nd->exe, nd->agent, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return fail_with("code object load (is libmirhi_kernels.hsaco of this build?)");
+    if (hsa_executable_freeze(nd->exe, nullptr) != HSA_STATUS_SUCCESS) return fail_with("executable freeze");
+    nd->ok = true;
+    return nd;
+}
+
+// the sRGB table of this copy of the code object (the HIP runtime's copy has its own: upload_srgb_lut)
+bool native_upload_symbol(mirhi::NativeDevice* nd, const char* name, const void* src, size_t bytes) {
+    hsa_executable_symbol_t sym;
+    if (hsa_executable_get_symbol_by_name(nd->exe, name, &nd->agent, &sym) != HSA_STATUS_SUCCESS) return false;
+    uint64_t addr = 0;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr) != HSA_STATUS_SUCCESS || !addr) return false;
+    return hsa_memory_copy(reinterpret_cast<void*>(addr), src, bytes) == HSA_STATUS_SUCCESS;
+}
+
+mirhi::NativeQueue* native_queue_open(mirhi::NativeDevice* nd) {
+    auto* nq = new mirhi::NativeQueue();
+    nq->nd = nd;
+    if (hsa_queue_create(nd->agent, NATIVE_QUEUE_PACKETS, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &nq->q) != HSA_STATUS_SUCCESS) { delete nq; return nullptr; }
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, NATIVE_RING_BYTES, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); (void)hsa_queue_destroy(nq->q); delete nq; return nullptr; }
+    nq->ring = static_cast<uint8_t*>(p); nq->ring_bytes = NATIVE_RING_BYTES;
+    if (hsa_signal_create(0, 0, nullptr, &nq->drain_sig) != HSA_STATUS_SUCCESS) { (void)hipFree(p); (void)hsa_queue_destroy(nq->q); delete nq; return nullptr; }
+    return nq;
+}
+void native_queue_close(mirhi::NativeQueue* nq) {
+    if (!nq) return;
+    (void)hsa_signal_destroy(nq->drain_sig);
+    (void)hsa_queue_destroy(nq->q);
+    (void)hipFree(nq->ring);
+    delete nq;
+}
+
+// every packet written to the queue so far has completed (a barrier packet with a completion signal, waited for on the host)
+void native_queue_drain(mirhi::NativeQueue* nq) {
+    if (!nq) return;
+    std::lock_guard<std::mutex> qlock(nq->mu);
+    if (nq->drained == nq->widx) return;
+    while (nq->widx - hsa_queue_load_read_index_relaxed(nq->q) >= NATIVE_QUEUE_PACKETS - 2) cpu_relax();
+    hsa_signal_store_relaxed(nq->drain_sig, 1);
+    auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(nq->q->base_address) + (nq->widx & (NATIVE_QUEUE_PACKETS - 1));
+    memset(reinterpret_cast<uint8_t*>(p) + 2, 0, sizeof *p - 2);
+    p->completion_signal = nq->drain_sig;
+    const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);
+    nq->widx++;
+    hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
+    hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)(nq->widx - 1));
+    while (hsa_signal_load_scacquire(nq->drain_sig) != 0) cpu_relax();
+    nq->drained = nq->widx;
+}
+}  // namespace
+
+hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, dim3 block, const void* args, size_t args_bytes, uint64_t signal) {
+    NativeDevice* nd = nq->nd;
+    const NativeKernel* k = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(nd->mu);
+        for (auto& e : nd->kernels) if (e.first == key) { k = &e.second; break; }
+        if (!k) {
+            hsa_executable_symbol_t sym;
+            const char* mangled = hipKernelNameRefByPtr(key, nullptr);         // the device-side symbol the HIP runtime registered for this kernel
+            if (!mangled) { (void)hipGetLastError(); return hipErrorInvalidDeviceFunction; }
+            const std::string name = std::string(mangled) + ".kd";
+            NativeKernel nk{};
+            if (hsa_executable_get_symbol_by_name(nd->exe, name.c_str(), &nd->agent, &sym) != HSA_STATUS_SUCCESS ||
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &nk.object) != HSA_STATUS_SUCCESS ||
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &nk.kernarg_bytes) != HSA_STATUS_SUCCESS ||
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &nk.lds_bytes) != HSA_STATUS_SUCCESS ||
+                hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &nk.scratch_bytes) != HSA_STATUS_SUCCESS)
+                return hipErrorInvalidDeviceFunction;
+            if (nk.scratch_bytes != 0) return hipErrorInvalidDeviceFunction;         // (no kernel of this library uses scratch; a queue of ours has none set up)
+            nd->kernels.emplace_back(key, nk);
+            k = &nd->kernels.back().second;
+        }
+    }
+    std::lock_guard<std::mutex> qlock(nq->mu);
+    const size_t explicit_bytes = (args_bytes + 7) & ~(size_t)7;
+    const size_t need = (std::max<size_t>(explicit_bytes + sizeof(ImplicitArgs), k->kernarg_bytes) + 63) & ~(size_t)63;
+    if (need > 4096 || explicit_bytes + sizeof(ImplicitArgs) > 4096) return hipErrorInvalidValue;
+    if (nq->ring_pos + need > nq->ring_bytes) nq->ring_pos = 0;
+    // (a ring slot comes round again after >= 256 KB / 4 KB = 64 ... typically > 1000 dispatches; the queue holds 1024 packets in order)
+    while (nq->widx - hsa_queue_load_read_index_relaxed(nq->q) >= NATIVE_QUEUE_PACKETS - 2) cpu_relax();
+    uint8_t* ka = nq->ring + nq->ring_pos;
+    nq->ring_pos += need;
+    alignas(16) uint8_t tmp[4096];
+    memcpy(tmp, args, args_bytes);
+    if (explicit_bytes > args_bytes) memset(tmp + args_bytes, 0, explicit_bytes - args_bytes);
+    ImplicitArgs im;
+    memset(&im, 0, sizeof im);
+    im.block_count[0] = grid.x; im.block_count[1] = grid.y; im.block_count[2] = grid.z;
+    im.group_size[0] = (uint16_t)block.x; im.group_size[1] = (uint16_t)block.y; im.group_size[2] = (uint16_t)block.z;
+    im.grid_dims = grid.z > 1 ? 3 : (grid.y > 1 ? 2 : 1);
+    memcpy(tmp + explicit_bytes, &im, sizeof im);
+    memcpy(ka, tmp, explicit_bytes + sizeof im);             // write-combined stores over the BAR
+    auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(nq->q->base_address) + (nq->widx & (NATIVE_QUEUE_PACKETS - 1));
+    p->setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+    p->workgroup_size_x = (uint16_t)block.x; p->workgroup_size_y = (uint16_t)block.y; p->workgroup_size_z = (uint16_t)block.z;
+    p->reserved0 = 0;
+    p->grid_size_x = grid.x * block.x; p->grid_size_y = grid.y * block.y; p->grid_size_z = grid.z * block.z;
+    p->private_segment_size = 0; p->group_segment_size = k->lds_bytes;
+    p->kernel_object = k->object; p->kernarg_address = ka; p->reserved2 = 0;
+    p->completion_signal.handle = signal;
+    // every kernel waits for the one before it on its queue (barrier bit), sees what the host and other agents wrote (system-scope acquire)
+    // and publishes what it wrote (system-scope release): the HIP runtime's defaults
+    const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                            (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);     // (also orders the kernarg stores: x86 stores stay in order, the doorbell store below flushes the write-combining buffers)
+    nq->widx++;
+    hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
+    __builtin_ia32_sfence();
+    hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)(nq->widx - 1));
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------------------------------------
 // objects
 // ------------------------------------------------------------------------------------------------
@@ -107,6 +295,9 @@ struct mirhi_device {
     std::vector<mirhi_cmd*> cmds;             // live command buffers (guarded by mu): lanes that go away are forgotten by all of them
     std::vector<mirhi_image*> images;         // live images (guarded by mu): a recording may outlive an attachment it names
     hipEvent_t order_event = nullptr;         // cross-lane attachment ordering (mirhi_image::last_stream)
+    // native dispatch (mirhi_native.h): one AQL queue per queue lane, opened when the lane first carries a native submit
+    NativeDevice* native = nullptr;
+    std::vector<NativeQueue*> native_lanes;
     mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
     std::string deferred_msg;
     double total_ms[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
@@ -150,6 +341,7 @@ struct mirhi_image {
     // stream, command buffer and submission that used this image as an attachment last: a submit on ANOTHER stream waits for it
     // (one event record + stream wait), unless a fence / wait_idle has reported that submission finished -- the frame loop's case.
     hipStream_t last_stream = nullptr; const mirhi_cmd* last_cmd = nullptr; uint64_t last_seq = 0;
+    NativeQueue* last_native = nullptr;      // ... or the AQL queue, when that submission was dispatched natively
 };
 
 struct mirhi_pipeline {
@@ -241,6 +433,7 @@ struct mirhi_cmd {
                                            //   loop that waits on its fences never takes
     uint64_t submit_seq = 0;               // submissions so far (a fence remembers which one it saw)
     std::atomic<int> queued{0};            // submissions handed to the submit thread and not yet issued by it
+    NativeQueue* last_native = nullptr;    // its last submission went out as AQL packets on this queue (else: last_stream)
     bool one_time = true;
     bool in_rendering = false;
     std::vector<RecordedPass> passes;
@@ -273,6 +466,8 @@ struct mirhi_fence {
     bool signaled = false;      // host-visible signaled state
     bool pending = false;       // an event record is outstanding
     std::atomic<bool> issued{true};   // false while its submission waits in the submit thread's queue (the event is recorded when it is issued)
+    hsa_signal_t native_sig{0};       // native dispatch: completion signal of the submission's last packet (1 -> 0), polled in host memory
+    bool native_wait = false;         //   the pending submission is waited for through it, not through `event`
     std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
     std::vector<uint64_t> seqs;    //   and which submission of each it was (mirhi_cmd::submit_seq)
     mirhi_result deferred = MIRHI_OK;   // status handed over by a listed command buffer that was destroyed / re-recorded since
@@ -343,6 +538,15 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
         hipError_t le = upload_srgb_lut(lut, d->stream);
         if (le == hipSuccess) le = hipStreamSynchronize(d->stream);
         if (le != hipSuccess) { if (d->owns_stream) (void)hipStreamDestroy(d->stream); delete d; return hip_fail(le, "sRGB table upload"); }
+        // native dispatch: the same kernels through our own AQL queues (mirhi_native.h); its copy of the code object has its own table
+        d->native = native_device_open(ordinal);
+        if (d->native->ok && !native_upload_symbol(d->native, "_ZN5mirhi10g_srgb_lutE", lut, sizeof lut)) { d->native->ok = false; d->native->why = "sRGB table symbol not found in the code object"; }
+        if (!d->native->ok && getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 2) {      // (2: required -- tests that must not pass on the fallback)
+            const std::string why = d->native->why;
+            if (d->owns_stream) (void)hipStreamDestroy(d->stream);
+            delete d->native; delete d;
+            return fail(MIRHI_ERR_LOADING, "Loading error: native dispatch unavailable: %s", why.c_str());
+        }
     }
     *out = d;
     if (getenv("MIRHI_SUBMIT_THREAD") && atoi(getenv("MIRHI_SUBMIT_THREAD")) != 0) (void)mirhi_device_set_submit_thread(d, 1);   // (test runs: every device with the thread on)
@@ -351,18 +555,29 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
 extern "C" mirhi_result mirhi_device_create(int32_t ordinal, mirhi_device** out) { return device_create_common(ordinal, nullptr, false, out); }
 extern "C" mirhi_result mirhi_device_create_on_stream(int32_t ordinal, void* stream, mirhi_device** out) { return device_create_common(ordinal, stream, true, out); }
 
-static inline void cpu_relax() { __builtin_ia32_pause(); }
 // every job handed to the submit thread has been issued to the GPU's queues (not: has finished)
 static void drain_submits(mirhi_device* dev) {
     if (!dev->sq_on) return;
     const uint64_t want = dev->sq_pushed.load(std::memory_order_acquire);
     while (dev->sq_done.load(std::memory_order_acquire) < want) cpu_relax();
 }
+
 static mirhi_result sync_all_lanes(mirhi_device* dev) {
     drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
+    for (NativeQueue* nq : dev->native_lanes) native_queue_drain(nq);
     for (hipStream_t st : dev->lanes) HIP_TRY(hipStreamSynchronize(st));
     return MIRHI_OK;
+}
+// the AQL queue of a queue lane (opened on first use); nullptr: native dispatch is not available
+static NativeQueue* native_lane(mirhi_device* dev, uint32_t lane) {
+    if (!dev->native || !dev->native->ok) return nullptr;
+    if (dev->native_lanes.size() <= lane) dev->native_lanes.resize(lane + 1, nullptr);
+    if (!dev->native_lanes[lane]) {
+        dev->native_lanes[lane] = native_queue_open(dev->native);
+        if (!dev->native_lanes[lane]) { dev->native->ok = false; dev->native->why = "could not open an AQL queue"; return nullptr; }
+    }
+    return dev->native_lanes[lane];
 }
 static mirhi_result check_status_words(mirhi_device* dev);
 extern "C" mirhi_result mirhi_device_set_submit_thread(mirhi_device* dev, uint32_t enable);
@@ -380,9 +595,11 @@ extern "C" mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t
     if (dev->lanes.size() > lanes) {
         // (a command buffer must not keep the handle of a stream that is about to go: ADVICE r2, mirhi_cmd::last_stream)
         std::lock_guard<std::mutex> lock(dev->mu);
-        for (mirhi_cmd* c : dev->cmds) { c->last_stream = nullptr; c->pending = false; }
+        for (mirhi_cmd* c : dev->cmds) { c->last_stream = nullptr; c->last_native = nullptr; c->pending = false; }
+        for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_native = nullptr; img->last_cmd = nullptr; }
     }
     while (dev->lanes.size() > lanes) { (void)hipStreamDestroy(dev->lanes.back()); dev->lanes.pop_back(); }
+    while (dev->native_lanes.size() > lanes) { native_queue_close(dev->native_lanes.back()); dev->native_lanes.pop_back(); }
     while (dev->lanes.size() < lanes) {
         hipStream_t st = nullptr;
         HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -402,6 +619,11 @@ extern "C" mirhi_result mirhi_device_destroy(mirhi_device* dev) {
     for (auto& e : dev->free_events) (void)hipEventDestroy(e);
     if (dev->frag_stats) (void)hipFree(dev->frag_stats);
     if (dev->order_event) (void)hipEventDestroy(dev->order_event);
+    for (NativeQueue* nq : dev->native_lanes) native_queue_close(nq);
+    if (dev->native) {
+        if (dev->native->exe.handle) (void)hsa_executable_destroy(dev->native->exe);
+        delete dev->native;
+    }
     if (dev->owns_stream) (void)hipStreamDestroy(dev->stream);
     delete dev;
     return MIRHI_OK;
@@ -809,6 +1031,7 @@ extern "C" mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane) 
     NULL_CHECK(cmd, "command buffer");
     if (lane >= cmd->dev->lanes.size()) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lane %u of %zu", lane, cmd->dev->lanes.size());
     drain_submits(cmd->dev);
+    for (NativeQueue* nq : cmd->dev->native_lanes) if (nq && nq == cmd->last_native) native_queue_drain(nq);
     if (cmd->last_stream) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
     HIP_TRY(hipStreamSynchronize(cmd->dev->lanes[cmd->lane < cmd->dev->lanes.size() ? cmd->lane : 0]));
     cmd->pending = false;
@@ -1281,6 +1504,9 @@ static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit = false) {
     while (!in_submit && cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     if (!cmd->pending) return MIRHI_OK;
     mirhi_device* dev = cmd->dev;
+    if (cmd->last_native) {
+        for (NativeQueue* nq : dev->native_lanes) if (nq == cmd->last_native) native_queue_drain(nq);
+    }
     bool live = false;
     for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
     if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
@@ -1460,7 +1686,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, stream));
         w.parity = 0;
         w.dirty = false;
-        cmd->last_stream = stream; cmd->pending = true;      // (a submit on another stream -- a batched one -- waits for the clears)
+        cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true;      // (a submit on another stream or queue waits for the clears)
     }
 
     // vertex pre-pass jobs: one per distinct (vertex range, camera, object, program class) of each scope
@@ -1643,7 +1869,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     }
     w.wide_eligible = any_wide_eligible;
     if ((r = pblock_commit(w, stream)) != MIRHI_OK) return r;
-    if (!w.pblock_direct) { cmd->last_stream = stream; cmd->pending = true; }     // (the copy is in the lane's stream)
+    if (!w.pblock_direct) { cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true; }     // (the copy is in the lane's stream)
     cmd->planned = cmd->passes;
     cmd->plan_split_rank = dev->split_rank; cmd->plan_split_world = dev->split_world;
     cmd->plan_valid = true;
@@ -1701,27 +1927,34 @@ static void for_each_attachment(mirhi_device* dev, const mirhi_cmd* c, F&& f) {
         for (mirhi_image* img : {pass.info.color_image, pass.info.depth_image, pass.info.prim_id_image})
             if (img && std::find(dev->images.begin(), dev->images.end(), img) != dev->images.end()) f(img);
 }
-// `c` is about to run on `stream`: anything that used one of its attachments last on another stream, and is not known to have finished, goes first.
-static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream_t stream) {
+// `c` is about to run on `stream` (or, natively, on `nq`): anything that used one of its attachments last somewhere else, and is not known
+// to have finished, goes first.  Between two HIP streams that is an event; with an AQL queue on either side the host waits (a frame loop
+// never gets here: its fences have told the library that the earlier frame is done).
+static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream_t stream, NativeQueue* nq = nullptr) {
     hipError_t err = hipSuccess;
     for_each_attachment(dev, c, [&](mirhi_image* img) {
-        if (img->last_stream && img->last_stream != stream && err == hipSuccess) {
-            bool live = false;
-            for (hipStream_t st : dev->lanes) live |= st == img->last_stream;
-            if (live) {
-                if (!dev->order_event) err = hipEventCreateWithFlags(&dev->order_event, hipEventDisableTiming);
-                if (err == hipSuccess) err = hipEventRecord(dev->order_event, img->last_stream);
-                if (err == hipSuccess) err = hipStreamWaitEvent(stream, dev->order_event, 0);
+        const bool elsewhere = nq ? (img->last_native != nq && (img->last_native || img->last_stream)) : (img->last_native != nullptr || (img->last_stream && img->last_stream != stream));
+        if (elsewhere && err == hipSuccess) {
+            if (img->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == img->last_native) native_queue_drain(q); }
+            else {
+                bool live = false;
+                for (hipStream_t st : dev->lanes) live |= st == img->last_stream;
+                if (live && nq) err = hipStreamSynchronize(img->last_stream);
+                else if (live) {
+                    if (!dev->order_event) err = hipEventCreateWithFlags(&dev->order_event, hipEventDisableTiming);
+                    if (err == hipSuccess) err = hipEventRecord(dev->order_event, img->last_stream);
+                    if (err == hipSuccess) err = hipStreamWaitEvent(stream, dev->order_event, 0);
+                }
             }
         }
-        img->last_stream = stream; img->last_cmd = c; img->last_seq = c->submit_seq;
+        img->last_stream = nq ? nullptr : stream; img->last_native = nq; img->last_cmd = c; img->last_seq = c->submit_seq;
     });
     if (err != hipSuccess) return hip_fail(err, "attachment ordering across queue lanes");
     return MIRHI_OK;
 }
 // submission `seq` of `c` has finished: its attachments need no ordering any more (unless something newer used them since)
 static void release_attachments(mirhi_device* dev, const mirhi_cmd* c, uint64_t seq) {
-    for_each_attachment(dev, c, [&](mirhi_image* img) { if (img->last_cmd == c && img->last_seq == seq) { img->last_stream = nullptr; img->last_cmd = nullptr; } });
+    for_each_attachment(dev, c, [&](mirhi_image* img) { if (img->last_cmd == c && img->last_seq == seq) { img->last_stream = nullptr; img->last_native = nullptr; img->last_cmd = nullptr; } });
 }
 
 static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd* const* cmds, mirhi_fence* fence);
@@ -1811,7 +2044,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     // dev->mu guards the bookkeeping (unchecked list, statistics, attachment ordering, timed-dispatch events), not the launches: with
     // the submit thread on, the render thread must be able to complete a fence while this thread is inside hipLaunchKernel
     std::unique_lock<std::mutex> lock(dev->mu);
-    const bool keep_locked = dev->profiling != 0;
+    bool keep_locked = dev->profiling != 0;
     // Batched form: the command buffers of one submit, when each is one plain rendering scope of the same shape and kernel variants
     // (the frames of a frame loop), share one vertex, one geometry and one raster launch on the first one's queue lane -- the
     // ramp-up and drain of a kernel and the latency chain of the geometry kernel are paid once per batch, not once per frame.
@@ -1833,9 +2066,25 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     // The fence rides on the submit's last dispatch (its completion signal: hipExtLaunchKernelGGL stop event) when there is one and
     // everything of the submit runs on one stream -- an event RECORD is a command of its own in the stream: 4.5 us of stream time and
     // a round trip of 12-14 us against 6-9 us (tools/microbench/fence_latency.hip).
+    // Native dispatch (mirhi_native.h): the submit's kernels go out as AQL packets on the lane's own queue -- when nothing of the submit
+    // needs the HIP stream: no timed dispatches, no batch, no tile split (the band exchange lives on HIP streams), no ordered segment
+    // (its clear is a HIP memset), every command buffer on one lane.
+    bool use_native = !batched && cmd_count >= 1 && dev->native && dev->native->ok && dev->profiling == 0 && dev->split_world == 1;
+    for (uint32_t i = 0; use_native && i < cmd_count; i++) {
+        use_native = cmds[i]->lane == cmds[0]->lane && cmds[i]->lane < dev->lanes.size();
+        for (const PassParams& P : cmds[i]->plan) use_native = use_native && !P.ordered_recs;
+    }
+    NativeQueue* nq = use_native ? native_lane(dev, cmds[0]->lane) : nullptr;
+    use_native = nq != nullptr;
+    if (use_native) keep_locked = true;       // (an AQL queue has one producer at a time, and a dispatch takes 0.2 us: the device lock stays held)
     hipEvent_t fence_stop = nullptr;
     bool fence_attached = false;
-    if (fence) {
+    if (fence) fence->native_wait = false;
+    if (fence && use_native) {
+        if (!fence->native_sig.handle && hsa_signal_create(0, 0, nullptr, &fence->native_sig) != HSA_STATUS_SUCCESS) return fail(MIRHI_ERR_DEVICE, "Vulkan error: hsa_signal_create for a fence failed");
+        hsa_signal_store_relaxed(fence->native_sig, 1);
+    }
+    if (fence && !use_native) {
         if (!fence->event) HIP_TRY(hipEventCreate(&fence->event));
         bool one_stream = cmd_count >= 1 && dev->profiling == 0 && !getenv("MIRHI_FENCE_RECORD");
         for (uint32_t i = 1; one_stream && i < cmd_count && !batched; i++) one_stream = cmds[i]->lane == cmds[0]->lane;
@@ -1851,7 +2100,8 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
         for (uint32_t i = 0; i < cmd_count; i++) {
             mirhi_cmd* c = cmds[i];
             if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
-            c->last_stream = stream; c->pending = true; c->submit_seq++;
+            if (c->pending && c->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
+            c->last_stream = stream; c->last_native = nullptr; c->pending = true; c->submit_seq++;
             { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
             if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
             P[i] = &c->plan[0];
@@ -1872,7 +2122,9 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     for (uint32_t i = 0; !batched && i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
-        if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));
+        if (c->pending && !use_native && c->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
+        if (c->pending && c->last_stream && (use_native || c->last_stream != stream)) HIP_TRY(hipStreamSynchronize(c->last_stream));
+        if (c->pending && use_native && c->last_native && c->last_native != nq) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
         // Frames in flight, this one included (command buffers submitted and not yet known to have finished).  The wide mesh variants trade
         // throughput for latency -- a frame alone on the chip finishes sooner (C3 raster 32 -> 25 us), four frames in flight leave each
         // other less room (C3 16.2 -> 19.8 us per frame) -- so a submit takes them only while the queue is shallow: the reference's
@@ -1880,8 +2132,8 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
         int in_flight = 1;
         for (const mirhi_cmd* o : dev->cmds) in_flight += (o != c && o->pending) ? 1 : 0;
         const bool allow_wide = in_flight <= 2 || getenv("MIRHI_RASTER_WIDE") != nullptr;
-        c->last_stream = stream; c->pending = true; c->submit_seq++;
-        { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
+        c->last_stream = use_native ? nullptr : stream; c->last_native = use_native ? nq : nullptr; c->pending = true; c->submit_seq++;
+        { const mirhi_result ro = order_attachments(dev, c, stream, use_native ? nq : nullptr); if (ro != MIRHI_OK) return ro; }
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
         for (size_t pi = 0; pi < c->plan.size(); pi++) {
             const PassParams& P = c->plan[pi];
@@ -1893,6 +2145,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             // as "no coverage" -- an all-zero record is a degenerate triangle whose edge functions are negative everywhere
             if (P.ordered_recs && P.ordered_count) HIP_TRY(hipMemsetAsync(P.ordered_recs, 0, (size_t)P.ordered_count * sizeof(TriRec), stream));
             LaunchTiming tv{}, tg{}, tc{}, tr{};
+            if (use_native) { tv.native = nq; tg.native = nq; tr.native = nq; }
             // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
             // untimed: a timed dispatch completes through its own signal and does not overlap its neighbours the way an untimed one does)
             const uint32_t only_lane = (dev->profiling >> 8) & 0xFFu;
@@ -1928,6 +2181,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             }
             if (timed && has_tiles) { mirhi_result r = timing_begin(dev, MIRHI_KERNEL_RASTER, c->lane, &tr); if (r != MIRHI_OK) return r; }
             if (fence_stop && i + 1 == cmd_count && pi + 1 == c->plan.size() && has_tiles) { tr.stop = fence_stop; fence_attached = true; }   // (never together with `timed`)
+            if (fence && use_native && i + 1 == cmd_count && pi + 1 == c->plan.size() && has_tiles) { tr.native_signal = fence->native_sig.handle; fence_attached = true; }
             if (!keep_locked) lock.unlock();
             le = launch_raster(P, dp, big_count, c->plan_programs[pi], stream, tr, allow_wide);
             if (!keep_locked) lock.lock();
@@ -1937,7 +2191,18 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             dev->stats.triangles_submitted += P.total_tris;
         }
     }
-    if (fence) {
+    if (fence && use_native) {
+        if (!fence_attached) {            // nothing of the submit carried the signal (no tiles to raster): wait here, the fence is signalled at once
+            native_queue_drain(nq);
+            hsa_signal_store_relaxed(fence->native_sig, 0);
+        }
+        fence->native_wait = true;
+        fence->pending = true; fence->signaled = false;
+        fence->cmds.assign(cmds, cmds + cmd_count);
+        fence->seqs.resize(cmd_count);
+        for (uint32_t i = 0; i < cmd_count; i++) fence->seqs[i] = cmds[i]->submit_seq;
+        fence->deferred = MIRHI_OK; fence->deferred_msg.clear();
+    } else if (fence) {
         if (!fence_attached) {
             // the fence follows the last command buffer's lane and waits for the other lanes used by this submit
             hipStream_t fstream = cmd_count ? cmds[cmd_count - 1]->last_stream : dev->stream;
@@ -2013,7 +2278,7 @@ static mirhi_result check_status_words(mirhi_device* dev) {
     for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
     dev->unchecked.clear();
     for (mirhi_cmd* c : dev->cmds) c->pending = false;       // (called with every lane synchronised)
-    for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_cmd = nullptr; }
+    for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_native = nullptr; img->last_cmd = nullptr; }
     if (dev->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = dev->deferred; g_last_error = dev->deferred_msg; } dev->deferred = MIRHI_OK; dev->deferred_msg.clear(); }
     return r;
 }
@@ -2054,6 +2319,16 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
         std::this_thread::sleep_for(std::chrono::nanoseconds(timeout_ns < 1000000000ull ? timeout_ns : 1000000000ull));
         return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
     }
+    if (f->native_wait) {
+        // native dispatch: the completion signal of the submission's last packet, a word in host memory (1 -> 0)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; it++) {
+            if (hsa_signal_load_scacquire(f->native_sig) == 0) { f->native_wait = false; return fence_complete(f); }
+            cpu_relax();
+            if ((it & 1023u) == 1023u && timeout_ns != UINT64_MAX && (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ns)
+                return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        }
+    }
     HIP_TRY(hipSetDevice(f->dev->ordinal));
     if (timeout_ns == UINT64_MAX) {
         // a frame loop's fence is due within microseconds: poll (60 ns per query) for a while before blocking in the runtime
@@ -2085,7 +2360,8 @@ extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
     if (f->pending) {   // resetting a fence that is still in flight is invalid in Vulkan; drain it first
         while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
         HIP_TRY(hipSetDevice(f->dev->ordinal));
-        HIP_TRY(hipEventSynchronize(f->event));
+        if (f->native_wait) { while (hsa_signal_load_scacquire(f->native_sig) != 0) cpu_relax(); f->native_wait = false; }
+        else HIP_TRY(hipEventSynchronize(f->event));
         (void)fence_complete(f);
     }
     f->signaled = false;
@@ -2095,6 +2371,11 @@ extern "C" mirhi_result mirhi_fence_status(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     if (f->signaled) return MIRHI_OK;
     if (!f->pending || !f->issued.load(std::memory_order_acquire)) return MIRHI_NOT_READY;
+    if (f->native_wait) {
+        if (hsa_signal_load_scacquire(f->native_sig) != 0) return MIRHI_NOT_READY;
+        f->native_wait = false; (void)fence_complete(f);
+        return MIRHI_OK;
+    }
     (void)hipSetDevice(f->dev->ordinal);
     hipError_t e = hipEventQuery(f->event);
     if (e == hipSuccess) { (void)fence_complete(f); return MIRHI_OK; }
@@ -2105,7 +2386,9 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     (void)hipSetDevice(f->dev->ordinal);
     while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
-    if (f->pending) (void)hipEventSynchronize(f->event);
+    if (f->pending && f->native_wait) { while (hsa_signal_load_scacquire(f->native_sig) != 0) cpu_relax(); }
+    else if (f->pending && f->event) (void)hipEventSynchronize(f->event);
+    if (f->native_sig.handle) (void)hsa_signal_destroy(f->native_sig);
     if (f->event) (void)hipEventDestroy(f->event);
     if (f->join) (void)hipEventDestroy(f->join);
     { std::lock_guard<std::mutex> lock(f->dev->mu); auto& v = f->dev->fences; v.erase(std::remove(v.begin(), v.end(), f), v.end()); }
@@ -2314,6 +2597,7 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
     drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
+    if (after && after->last_native) for (NativeQueue* nq : dev->native_lanes) if (nq == after->last_native) native_queue_drain(nq);     // (frames of a split go through HIP; one rendered before the split was set may not have)
     hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
     hipStream_t stream = comm->stream;
     const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;

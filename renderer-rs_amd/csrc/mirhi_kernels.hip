@@ -42,17 +42,24 @@ hipError_t upload_srgb_lut(const float* lut, hipStream_t stream) {
     return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_srgb_lut), lut, 256 * sizeof(float), 0, hipMemcpyHostToDevice, stream);
 }
 
-// A plain launch, or -- when the caller wants the dispatch timed -- one with an event pair attached to the dispatch itself.
+// failure of a native dispatch inside the launch wrappers below (they report it with their return value)
+static thread_local hipError_t t_native_err = hipSuccess;
+static inline hipError_t launch_result() { const hipError_t e = t_native_err; t_native_err = hipSuccess; return e != hipSuccess ? e : hipGetLastError(); }
+// A plain launch, or -- when the caller wants the dispatch timed -- one with an event pair attached to the dispatch itself, or a native dispatch.
 #define MIRHI_LAUNCH(kernel, grid, block, stream, t, ...)                                                               \
     do {                                                                                                                \
-        if ((t).start || (t).stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \
+        if ((t).native) {                                                                                               \
+            const hipError_t ne__ = native_launch((t).native, reinterpret_cast<const void*>(+kernel), grid, block, (t).native_signal, __VA_ARGS__); \
+            if (ne__ != hipSuccess) t_native_err = ne__;                                                                \
+        }                                                                                                               \
+        else if ((t).start || (t).stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                           \
     } while (0)
 
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
     if (P.vs_total_slots == 0) return hipSuccess;
     MIRHI_LAUNCH(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), stream, t, dev_params);
-    return hipGetLastError();
+    return launch_result();
 }
 
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
@@ -62,7 +69,7 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
     // (more waves than the chip holds at five per SIMD: the occupancy-oriented variant)
     if (blocks > 5u * 1024u) MIRHI_LAUNCH(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
     else MIRHI_LAUNCH(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
-    return hipGetLastError();
+    return launch_result();
 }
 
 template <int KEYED, int TP, int TEAMS = 1>
@@ -95,7 +102,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
         else if (programs == 3) MIRHI_LAUNCH(ordered_kernel<3>, og, ob, stream, t, dev_params, HO);
         else if (programs >= 4) MIRHI_LAUNCH(ordered_kernel<4>, og, ob, stream, t, dev_params, HO);
         else MIRHI_LAUNCH(ordered_kernel<1>, og, ob, stream, t, dev_params, HO);
-        return hipGetLastError();
+        return launch_result();
     }
     const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
@@ -116,7 +123,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     }
     else if (P.tp_max_area) { if (plain) launch_raster_k<0, 1>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); else launch_raster_k<1, 1>(dev_params, H, programs, grid, stream, t, P.alpha_scope != 0u); }
     else { if (plain) launch_raster_k<0, 0>(dev_params, H, programs, grid, stream, t); else launch_raster_k<1, 0>(dev_params, H, programs, grid, stream, t); }
-    return hipGetLastError();
+    return launch_result();
 }
 
 // ---- batched launches --------------------------------------------------------------------------------------------
@@ -137,7 +144,7 @@ hipError_t launch_vertex_batch(const PassParams* const* P, const PassParams* con
     for (uint32_t i = 0; i < n; i++) { B.params[i] = dev_params[i]; most = P[i]->vs_total_slots > most ? P[i]->vs_total_slots : most; }
     if (most == 0) return hipSuccess;
     hipLaunchKernelGGL(vertex_kernel_batch, dim3(most / GEOM_THREADS, n), dim3(GEOM_THREADS), 0, stream, B);
-    return hipGetLastError();
+    return launch_result();
 }
 
 hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* const* dev_params, uint32_t n, hipStream_t stream) {
@@ -152,7 +159,7 @@ hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* c
     if (most == 0) return hipSuccess;
     if (total > 5u * 1024u) hipLaunchKernelGGL(geometry_kernel_batch<7>, dim3(most, n), dim3(GEOM_THREADS), 0, stream, B);
     else hipLaunchKernelGGL(geometry_kernel_batch<5>, dim3(most, n), dim3(GEOM_THREADS), 0, stream, B);
-    return hipGetLastError();
+    return launch_result();
 }
 
 template <int KEYED, int TP, int TEAMS = 1>
@@ -188,7 +195,7 @@ hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* co
     else if (P.tp_max_area) launch_raster_batch_k<0, 1>(B, programs, grid, stream, t);
     else launch_raster_batch_k<0, 0>(B, programs, grid, stream, t);
     (void)plain;
-    return hipGetLastError();
+    return launch_result();
 }
 bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && P.zmask == 0xFFFFFFFFu && P.xcd_swizzle <= 1u && !P.ordered_recs && !P.alpha_scope && !P.raster_wide; }
 
@@ -197,14 +204,14 @@ hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_para
     if (rows == 0 || P.tiles_x == 0 || P.ordered_recs) return hipSuccess;
     const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
     MIRHI_LAUNCH(fragment_count_kernel, dim3(P.tiles_x, rows), dim3(RASTER_THREADS), stream, t, dev_params, H);
-    return hipGetLastError();
+    return launch_result();
 }
 
 hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream) {
     if (!pixels) return hipSuccess;
     const uint32_t blocks = (pixels + RASTER_THREADS * 16u - 1u) / (RASTER_THREADS * 16u);
     hipLaunchKernelGGL(winner_count_kernel, dim3(blocks), dim3(RASTER_THREADS), 0, stream, prim, pixels, stats);
-    return hipGetLastError();
+    return launch_result();
 }
 
 #ifdef MIRHI_STAMPS

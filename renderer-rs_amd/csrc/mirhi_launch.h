@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mirhi_device.h"
+#include "mirhi_native.h"
 
 namespace mirhi {
 // P: host copy (launch geometry); dev_params: the same parameters in device memory, read by the kernels.
@@ -10,7 +11,9 @@ namespace mirhi {
 // is then the kernel's own begin -> end on the GPU clock, what rocprofv3 --kernel-trace reports, with no event-record
 // commands of its own in the stream.  Null events: a plain launch.  A stop event alone: the dispatch's completion signal, which is
 // how a submit's fence is signalled (mirhi_queue_submit).
-struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; };
+// native: dispatch on this AQL queue instead of a HIP stream (mirhi_native.h); native_signal: an hsa_signal_t handle decremented at the
+// kernel's end (a submit's fence), 0 = none.  Never together with start / stop.
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; };
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
