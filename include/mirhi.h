@@ -313,7 +313,8 @@ typedef struct {
     uint32_t last_big_list;         /* triangles that took the large/overflow list in the last finished scope */
     uint32_t last_status;           /* device status word of the last finished scope (0 = ok; bit 2: the bin pool ran out and is grown) */
     uint32_t last_bin_pages;        /* 2 KB bin pages the last finished scope took from the pool (beyond each tile's fixed first page) */
-    uint32_t reserved;
+    uint32_t native_dispatches;     /* kernels this device dispatched as AQL packets on its own ROCr queues (csrc/mirhi_native.h) instead of through
+                                       HIP launches (low 32 bits of the count); 0 on a device whose native dispatcher could not start */
 } mirhi_device_stats;
 mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out);
 

@@ -151,7 +151,7 @@ class DispatchTime(C.Structure):
 
 class DeviceStats(C.Structure):
     _fields_ = [("frames_submitted", C.c_uint64), ("triangles_submitted", C.c_uint64), ("workspace_bytes", C.c_uint64),
-                ("last_big_list", C.c_uint32), ("last_status", C.c_uint32), ("last_bin_pages", C.c_uint32), ("reserved", C.c_uint32)]
+                ("last_big_list", C.c_uint32), ("last_status", C.c_uint32), ("last_bin_pages", C.c_uint32), ("native_dispatches", C.c_uint32)]
 
 
 class RhiError(RuntimeError):

@@ -95,6 +95,7 @@ struct NativeDevice {
     std::vector<std::pair<const void*, NativeKernel>> kernels;      // by host function address (a handful: linear search)
     bool ok = false;
     std::string why;
+    std::atomic<uint64_t> dispatches{0};
 };
 struct NativeQueue {
     NativeDevice* nd = nullptr;
@@ -205,7 +206,7 @@ void native_queue_drain(mirhi::NativeQueue* nq) {
 }
 }  // namespace
 
-hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, dim3 block, const void* args, size_t args_bytes, uint64_t signal) {
+hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, dim3 block, const void* args, size_t args_bytes, uint64_t signal, uint32_t flags) {
     NativeDevice* nd = nq->nd;
     const NativeKernel* k = nullptr;
     {
@@ -255,10 +256,12 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     p->private_segment_size = 0; p->group_segment_size = k->lds_bytes;
     p->kernel_object = k->object; p->kernarg_address = ka; p->reserved2 = 0;
     p->completion_signal.handle = signal;
-    // every kernel waits for the one before it on its queue (barrier bit), sees what the host and other agents wrote (system-scope acquire)
-    // and publishes what it wrote (system-scope release): the HIP runtime's defaults
+    // every kernel waits for the one before it on its queue (barrier bit); its fences are agent scope unless the caller asked for system scope
+    const uint16_t acq = (flags & NATIVE_ACQUIRE_SYSTEM) || signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    const uint16_t rel = (flags & NATIVE_RELEASE_SYSTEM) || signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                            (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                            (uint16_t)(acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (uint16_t)(rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    nd->dispatches.fetch_add(1, std::memory_order_relaxed);
     __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);     // (also orders the kernarg stores: x86 stores stay in order, the doorbell store below flushes the write-combining buffers)
     nq->widx++;
     hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
@@ -2145,7 +2148,14 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             // as "no coverage" -- an all-zero record is a degenerate triangle whose edge functions are negative everywhere
             if (P.ordered_recs && P.ordered_count) HIP_TRY(hipMemsetAsync(P.ordered_recs, 0, (size_t)P.ordered_count * sizeof(TriRec), stream));
             LaunchTiming tv{}, tg{}, tc{}, tr{};
-            if (use_native) { tv.native = nq; tg.native = nq; tr.native = nq; }
+            if (use_native) {
+                tv.native = nq; tg.native = nq; tr.native = nq;
+                // the scope's first kernels see what the host wrote (parameter block, buffers uploaded since); its raster kernel publishes the frame
+                const bool sys = getenv("MIRHI_NATIVE_SYSTEM_SCOPE") != nullptr;          // (A/B runs: system scope on every packet)
+                tv.native_flags = NATIVE_ACQUIRE_SYSTEM | (sys ? NATIVE_RELEASE_SYSTEM : 0u);
+                tg.native_flags = ((P.vs_total_slots == 0u || sys) ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);      // (behind a vertex kernel: that one took the acquire)
+                tr.native_flags = NATIVE_RELEASE_SYSTEM | (sys ? NATIVE_ACQUIRE_SYSTEM : 0u);
+            }
             // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
             // untimed: a timed dispatch completes through its own signal and does not overlap its neighbours the way an untimed one does)
             const uint32_t only_lane = (dev->profiling >> 8) & 0xFFu;
@@ -2480,6 +2490,7 @@ extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_s
     drain_submits(dev);
     std::lock_guard<std::mutex> lock(dev->mu);
     *out = dev->stats;
+    out->native_dispatches = dev->native ? (uint32_t)dev->native->dispatches.load(std::memory_order_relaxed) : 0u;
     return MIRHI_OK;
 }
 

@@ -49,7 +49,7 @@ static inline hipError_t launch_result() { const hipError_t e = t_native_err; t_
 #define MIRHI_LAUNCH(kernel, grid, block, stream, t, ...)                                                               \
     do {                                                                                                                \
         if ((t).native) {                                                                                               \
-            const hipError_t ne__ = native_launch((t).native, reinterpret_cast<const void*>(+kernel), grid, block, (t).native_signal, __VA_ARGS__); \
+            const hipError_t ne__ = native_launch((t).native, reinterpret_cast<const void*>(+kernel), grid, block, (t).native_signal, (t).native_flags, __VA_ARGS__); \
             if (ne__ != hipSuccess) t_native_err = ne__;                                                                \
         }                                                                                                               \
         else if ((t).start || (t).stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, (t).start, (t).stop, 0, __VA_ARGS__);     \

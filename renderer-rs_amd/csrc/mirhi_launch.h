@@ -13,7 +13,7 @@ namespace mirhi {
 // how a submit's fence is signalled (mirhi_queue_submit).
 // native: dispatch on this AQL queue instead of a HIP stream (mirhi_native.h); native_signal: an hsa_signal_t handle decremented at the
 // kernel's end (a submit's fence), 0 = none.  Never together with start / stop.
-struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; };
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; uint32_t native_flags = 0; };
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)

@@ -18,7 +18,11 @@ struct NativeQueue;       // one AQL queue (a queue lane of a device)
 // one kernel dispatch: `key` the host address of the __global__ function (its device-side symbol is asked of the HIP runtime once:
 // hipKernelNameRefByPtr), `args` the explicit arguments packed as the kernel ABI lays them out; `signal` (an hsa_signal_t handle, 0 = none)
 // is decremented when the kernel has finished
-hipError_t native_enqueue(NativeQueue* q, const void* key, dim3 grid, dim3 block, const void* args, size_t args_bytes, uint64_t signal);
+// flags: memory scope of the packet's acquire / release fences -- agent scope unless asked for system scope (the first kernel of a submit
+// must see what the host wrote, the last one must publish the frame to the host and the copy engines; the ones in between only talk
+// to each other: a system-scope fence on every packet cost the frame loop 4 - 7 %)
+enum : uint32_t { NATIVE_ACQUIRE_SYSTEM = 1u, NATIVE_RELEASE_SYSTEM = 2u };
+hipError_t native_enqueue(NativeQueue* q, const void* key, dim3 grid, dim3 block, const void* args, size_t args_bytes, uint64_t signal, uint32_t flags);
 
 // packs kernel arguments the way the compiler lays out the explicit kernarg segment: each at its natural alignment
 struct KernargPacker {
@@ -31,9 +35,9 @@ struct KernargPacker {
     }
 };
 template <typename... A>
-inline hipError_t native_launch(NativeQueue* q, const void* key, dim3 grid, dim3 block, uint64_t signal, const A&... a) {
+inline hipError_t native_launch(NativeQueue* q, const void* key, dim3 grid, dim3 block, uint64_t signal, uint32_t flags, const A&... a) {
     KernargPacker p;
     (p.push(a), ...);
-    return native_enqueue(q, key, grid, block, p.bytes, p.size, signal);
+    return native_enqueue(q, key, grid, block, p.bytes, p.size, signal, flags);
 }
 }  // namespace mirhi

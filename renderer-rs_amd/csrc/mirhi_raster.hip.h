@@ -150,6 +150,14 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
     return tile_rec_core(out, X, Y, 256 * ox + 128, 256 * oy + 128, bx0, bx1, by0, by1, (float)ox, (float)oy, w1.z, w1.w, w2.x, w2.y, w2.z & 0x80000000u);
 }
 
+// The colour target is written once and never read back by this kernel: streaming ("nt") stores keep its 8 - 33 MB from piling up as
+// dirty lines in the L2s, which the end-of-kernel release would have to write back before the frame's fence can signal.
+#ifndef MIRHI_PLAIN_TARGET_STORES
+__device__ __forceinline__ void store_target(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ void store_target(uint32_t* p, uint32_t v) { *p = v; }
+#endif
+
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
 // KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied);
 //         2: predicate against the scope's initial depth (see DESIGN.md "Depth key").
@@ -695,7 +703,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
                 const size_t pix = (size_t)py * P.width + px;
                 if (write_color) {
                     if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]);
-                    else reinterpret_cast<uint32_t*>(P.color)[pix] = P.clear_packed;
+                    else store_target(reinterpret_cast<uint32_t*>(P.color) + pix, P.clear_packed);
                     if (P.prim_out) P.prim_out[pix] = NO_PRIM;
                 }
                 if (write_depth) P.depth[pix] = __uint_as_float(P.clear_depth_bits);
@@ -830,10 +838,10 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
             uint8_t* row1 = row0 + (size_t)BLOCK * width * 4u;                 // the lower pair of blocks: uniform base
             const uint32_t off = (py0 * width + px0) * 4u;
             if ((tx + 1u) * TILE <= width && (ty + 1u) * TILE <= height && !R->color_load) {   // wave-uniform: interior tile
-                *reinterpret_cast<uint32_t*>(row0 + off) = st.idk[0] != init_idk ? flat4[0] : clear_packed;
-                *reinterpret_cast<uint32_t*>(row0 + off + 4u * BLOCK) = st.idk[1] != init_idk ? flat4[1] : clear_packed;
-                *reinterpret_cast<uint32_t*>(row1 + off) = st.idk[2] != init_idk ? flat4[2] : clear_packed;
-                *reinterpret_cast<uint32_t*>(row1 + off + 4u * BLOCK) = st.idk[3] != init_idk ? flat4[3] : clear_packed;
+                store_target(reinterpret_cast<uint32_t*>(row0 + off), st.idk[0] != init_idk ? flat4[0] : clear_packed);
+                store_target(reinterpret_cast<uint32_t*>(row0 + off + 4u * BLOCK), st.idk[1] != init_idk ? flat4[1] : clear_packed);
+                store_target(reinterpret_cast<uint32_t*>(row1 + off), st.idk[2] != init_idk ? flat4[2] : clear_packed);
+                store_target(reinterpret_cast<uint32_t*>(row1 + off + 4u * BLOCK), st.idk[3] != init_idk ? flat4[3] : clear_packed);
             } else {
                 const uint32_t color_load = R->color_load;
 #pragma unroll
@@ -841,7 +849,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
                     const uint32_t px = px0 + (uint32_t)(b & 1) * BLOCK, py = py0 + (uint32_t)(b >> 1) * BLOCK;
                     const bool won = st.idk[b] != init_idk;
                     if (px < width && py < height && (won || !color_load))
-                        *reinterpret_cast<uint32_t*>((b >> 1 ? row1 : row0) + off + 4u * BLOCK * (uint32_t)(b & 1)) = won ? flat4[b] : clear_packed;
+                        store_target(reinterpret_cast<uint32_t*>((b >> 1 ? row1 : row0) + off + 4u * BLOCK * (uint32_t)(b & 1)), won ? flat4[b] : clear_packed);
                 }
             }
             STAMP(4);
@@ -887,7 +895,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
         if (!inb) continue;
         if (!(none && P.color_load)) {
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
-            else reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));
+            else store_target(reinterpret_cast<uint32_t*>(P.color) + pix, none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col)));
         }
         if (P.prim_out && !(none && P.color_load)) P.prim_out[pix] = prim;     // LOAD keeps what an earlier scope / segment wrote
         if (P.depth && P.depth_store) {

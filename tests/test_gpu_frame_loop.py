@@ -191,3 +191,22 @@ def test_submit_thread_keeps_fence_and_error_semantics(mirhi, oracle, scenes):
     for f in fences:
         f.destroy()
     dev.destroy()
+
+
+def test_native_dispatch_carries_the_frame_loop(mirhi, scenes):
+    """The kernels of a plain submit go out as AQL packets on the library's own ROCr queues (csrc/mirhi_native.h): the device counts them.
+    A timed (profiling) submit goes through HIP launches and does not."""
+    dev = mirhi.Device(0)
+    scene = scenes.random_triangles(2000, 640, 360, seed=4)
+    res = mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB)
+    f = mirhi.Fence(dev)
+    n0 = dev.stats().native_dispatches
+    for _ in range(5):
+        res.render(f); f.wait(); f.reset()
+    n1 = dev.stats().native_dispatches
+    assert n1 - n0 == 10, f"expected 5 frames x (geometry + raster) native dispatches, counted {n1 - n0}"
+    dev.set_profiling(mirhi.Profile.TIMING)
+    res.render(f); f.wait(); f.reset()
+    dev.set_profiling(0)
+    assert dev.stats().native_dispatches == n1
+    res.destroy(); f.destroy(); dev.destroy()
