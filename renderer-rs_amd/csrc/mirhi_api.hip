@@ -137,6 +137,10 @@ mirhi::NativeDevice* native_device_open(int ordinal) {
     auto* nd = new mirhi::NativeDevice();
     auto fail_with = [&](const std::string& w) { nd->why = w; return nd; };
     if (getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 0) return fail_with("switched off (MIRHI_NATIVE_DISPATCH=0)");
+    // rocprofv3 --pmc rewrites the packets of the queues it intercepts; a process under counter collection hung at its first hand-written packet
+    // (round 3, tools/collect_profiles.sh) -- under it every launch goes through HIP (the kernels and their counters are the same).  --kernel-trace alone is fine.
+    if (getenv("ROCPROF_COUNTER_COLLECTION") && !(getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 2))
+        return fail_with("rocprofv3 counter collection is on in this process");
     if (hsa_init() != HSA_STATUS_SUCCESS) return fail_with("hsa_init failed");
     int bus = 0, devid = 0;
     if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, ordinal) != hipSuccess || hipDeviceGetAttribute(&devid, hipDeviceAttributePciDeviceId, ordinal) != hipSuccess) { (void)hipGetLastError(); return fail_with("no PCI id for the HIP device"); }

@@ -152,11 +152,28 @@ __device__ __forceinline__ bool make_tile_rec(uint4 out[4], uint32_t& box, const
 
 // The colour target is written once and never read back by this kernel: streaming ("nt") stores keep its 8 - 33 MB from piling up as
 // dirty lines in the L2s, which the end-of-kernel release would have to write back before the frame's fence can signal.
+// A streaming store that leaves a 64-byte line half written is paid twice at the memory (C4's raster kernel: 33 -> 60 MB written when the resolve
+// stored one 4-byte pixel per lane and 8x8 block, i.e. 32-byte row segments): the resolve pairs the two side-by-side blocks of a wave and stores
+// 8 bytes per lane, 64-byte row segments (store_pair); a lone 32-byte segment (the wide variant with one block per wave, edge tiles) stays a plain store.
 #ifndef MIRHI_PLAIN_TARGET_STORES
 __device__ __forceinline__ void store_target(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+typedef unsigned long long target_pair_t __attribute__((aligned(4)));
+__device__ __forceinline__ void store_target2(uint32_t* p, uint32_t lo, uint32_t hi) { __builtin_nontemporal_store(((unsigned long long)hi << 32) | lo, reinterpret_cast<target_pair_t*>(p)); }
 #else
 __device__ __forceinline__ void store_target(uint32_t* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void store_target2(uint32_t* p, uint32_t lo, uint32_t hi) { p[0] = lo; p[1] = hi; }
 #endif
+// The two horizontally adjacent 8x8 blocks of a wave (left block's packed colours in `left`, right block's in `right`, lane = (x = lane & 7, y = lane >> 3) of its
+// block) as ONE store of 8 bytes per lane: lanes x < 4 take pixels 2x, 2x + 1 of the left block, lanes x >= 4 pixels 2(x - 4), 2(x - 4) + 1 of the right one --
+// every row of the 16-pixel strip goes out as one 64-byte segment.  row_left: this lane's row start + the LEFT block's first pixel, in pixels.
+__device__ __forceinline__ void store_pair(uint32_t* target, uint32_t row_left, uint32_t left, uint32_t right, uint32_t lane) {
+    const uint32_t x = lane & 7u;
+    const int src = (int)((lane & ~7u) | ((x & 3u) << 1));
+    const uint32_t la = (uint32_t)__shfl((int)left, src), lb = (uint32_t)__shfl((int)left, src + 1);
+    const uint32_t ra = (uint32_t)__shfl((int)right, src), rb = (uint32_t)__shfl((int)right, src + 1);
+    const bool lhs = x < 4u;
+    store_target2(target + row_left + (lhs ? 2u * x : 8u + 2u * (x - 4u)), lhs ? la : ra, lhs ? lb : rb);
+}
 
 // coverage + depth resolve of one record against the 4 blocks (8x8 px each) this wave owns.
 // KEYED = 0: depth key is the raw float bits (LESS / LESS_OR_EQUAL); 1: generic (zflip / zmask applied);
@@ -703,7 +720,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
                 const size_t pix = (size_t)py * P.width + px;
                 if (write_color) {
                     if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(P.clear_color[0], P.clear_color[1], P.clear_color[2], P.clear_color[3]);
-                    else store_target(reinterpret_cast<uint32_t*>(P.color) + pix, P.clear_packed);
+                    else reinterpret_cast<uint32_t*>(P.color)[pix] = P.clear_packed;         // (plain: four 32-byte segments per lane pair up in the L2)
                     if (P.prim_out) P.prim_out[pix] = NO_PRIM;
                 }
                 if (write_depth) P.depth[pix] = __uint_as_float(P.clear_depth_bits);
@@ -856,6 +873,8 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
             return;
         }
     }
+    uint32_t held = 0;                 // packed colour of the pair's left (even) block, until the right one is shaded
+    bool held_all = false;             //   ... and every lane of the wave writes it (no pixel outside the target, none kept by LOAD)
 #pragma unroll 1
     for (int b = 0; b < NB; b++) {
         if (TEAMS > 1 && !solo && (uint32_t)(b * TEAMS) / 4u != team) continue;      // another team shades this block
@@ -892,10 +911,23 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
             }
             todo &= ~__ballot(mine);
         }
+        if (P.color_format != 2 && NB >= 2) {
+            // 8-bit target: the wave's two side-by-side blocks leave as one 8-byte store per lane (store_pair) when every lane of both writes its pixel
+            // (an interior tile without LOAD: the usual case); otherwise pixel by pixel, plain stores
+            const bool wr = inb && !(none && P.color_load);
+            const uint32_t packed = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));
+            const bool all = __ballot(wr) == ~0ull;
+            if ((b & 1) == 0) { held = packed; held_all = all; if (!all && wr) reinterpret_cast<uint32_t*>(P.color)[pix] = packed; }
+            else if (all && held_all) store_pair(reinterpret_cast<uint32_t*>(P.color), py * P.width + (px - (uint32_t)BLOCK) - (lane & 7u), held, packed, lane);
+            else {
+                if (held_all) reinterpret_cast<uint32_t*>(P.color)[pix - (size_t)BLOCK] = held;      // (the left block was complete, this one is not)
+                if (wr) reinterpret_cast<uint32_t*>(P.color)[pix] = packed;
+            }
+        }
         if (!inb) continue;
         if (!(none && P.color_load)) {
             if (P.color_format == 2) reinterpret_cast<float4*>(P.color)[pix] = make_float4(col.x, col.y, col.z, col.w);
-            else store_target(reinterpret_cast<uint32_t*>(P.color) + pix, none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col)));
+            else if (NB < 2) reinterpret_cast<uint32_t*>(P.color)[pix] = none ? P.clear_packed : (flat ? flat : pack_bgra8_srgb(col));      // (one block per wave: a lone 32-byte segment)
         }
         if (P.prim_out && !(none && P.color_load)) P.prim_out[pix] = prim;     // LOAD keeps what an earlier scope / segment wrote
         if (P.depth && P.depth_store) {

@@ -8,7 +8,7 @@
 #   bench_*     plain bench lines (no tool attached): the driver's command, and the other BASELINE configs
 # tools/make_profile_summaries.py <tag> turns the raw CSVs into the files committed under profiles/.
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -23,5 +23,9 @@ done
 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --timeline-out $out/timeline_in_flight.json > $out/bench_default.json 2> $out/bench_default.err
 for w in c3 c4 c5; do python3 bench.py --workload $w --cpu-seconds 8 > $out/bench_$w.json 2>/dev/null; echo "bench $w done"; done
-find $out -name "*.csv" | head -30
+# summaries are made HERE (the raw traces are too big to travel back), the bulky raw files dropped
+python3 tools/make_profile_summaries.py $tag $out/summary > $out/summary.log 2>&1 || tail -5 $out/summary.log
+find $out -name "*kernel_trace.csv" -size +2M -delete
+find $out -name "*.db" -delete
+du -sh $out
 tail -c 400 $out/bench_default.json

@@ -4,7 +4,10 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
-dst = os.path.join(root, "profiles")
+# second argument: where to write (default profiles/).  On the GPU box the raw traces are too big to travel back (gpurun merges <= 64 MiB), so
+# tools/collect_profiles.sh runs this there into gpurun_out/prof_<tag>/summary and drops the raw trace; the files are then copied into profiles/ here.
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
