@@ -3,6 +3,7 @@ parts that need no GPU behave like the reference (defaults, enum order, error co
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -151,3 +152,26 @@ def test_rust_wrapper_crate_only_uses_what_the_sys_crate_declares():
     cmd = open(os.path.join(ROOT, "bindings", "rust", "renderer-rhi-hip", "src", "command.rs")).read()
     for fld in set(re.findall(r"\bri\.(\w+) =", cmd)):
         assert fld in fields["mirhi_rendering_info"], fld
+
+
+def test_frame_loop_library_exports_every_declared_symbol(mirhi, tmp_path):
+    """include/mirhost.h (the reference's draw-submit loop as native host code over the C ABI): libmirhost.so loads next to libmirhi.so and exports
+    every function the header declares; every declaration names what it mirrors in crates/renderer."""
+    from renderer_rs_amd import frameloop
+    text = open(os.path.join(ROOT, "include", "mirhost.h")).read()
+    body = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    names = re.findall(r"\b(mirhost_\w+)\s*\(", body)
+    assert set(names) >= {"mirhost_frame_loop_create", "mirhost_frame_loop_run", "mirhost_frame_loop_last_image", "mirhost_frame_loop_phase_seconds",
+                          "mirhost_frame_loop_destroy", "mirhost_last_error_message"}
+    lib = C.CDLL(frameloop.build())
+    missing = [n for n in set(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/mirhost.h but not exported: {missing}"
+    assert "renderer.rs:367-449" in text and "frame_manager.rs:299-539" in text
+    # the ctypes mirror of the two structs has the C layout gcc gives the header
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mirhost.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", sizeof(mirhost_draw), '
+                   'sizeof(mirhost_frame_desc), offsetof(mirhost_draw, count), offsetof(mirhost_frame_desc, draws)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(frameloop.HostDraw), C.sizeof(frameloop.FrameDesc), frameloop.HostDraw.count.offset, frameloop.FrameDesc.draws.offset]
