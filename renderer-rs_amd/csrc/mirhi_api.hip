@@ -104,6 +104,7 @@ struct NativeQueue {
     size_t ring_bytes = 0, ring_pos = 0;
     uint64_t widx = 0, drained = 0;          // packets written so far / packets known to have completed
     hsa_signal_t drain_sig{};
+    uint64_t seen_foreign = 0;               // mirhi_device::foreign_writes at this queue's last system-scope acquire
     std::mutex mu;                           // one producer at a time (a host thread that waits for the queue also writes a packet)
 };
 }  // namespace mirhi
@@ -261,7 +262,9 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     p->kernel_object = k->object; p->kernarg_address = ka; p->reserved2 = 0;
     p->completion_signal.handle = signal;
     // every kernel waits for the one before it on its queue (barrier bit); its fences are agent scope unless the caller asked for system scope
-    const uint16_t acq = (flags & NATIVE_ACQUIRE_SYSTEM) || signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    // (a system-scope ACQUIRE costs the packet 2.6 us -- tools/microbench/hsa/hsa_dispatch.cpp -- so it is asked for only when something
+    // outside this agent wrote memory since the queue's last one; a completion signal asks for a system-scope RELEASE: the host is told)
+    const uint16_t acq = (flags & NATIVE_ACQUIRE_SYSTEM) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     const uint16_t rel = (flags & NATIVE_RELEASE_SYSTEM) || signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (uint16_t)(acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (uint16_t)(rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
@@ -288,6 +291,10 @@ struct mirhi_device {
     std::vector<hipStream_t> lanes;          // submit streams; lanes[0] == stream
     uint32_t next_lane = 0;
     std::atomic<int> children{0};
+    // Bumped whenever something that is not a kernel of this library writes device memory the kernels may read (copy engines, HIP's
+    // memsets, RCCL, memory wrapped from outside): the next scope on each AQL queue then opens with a system-scope acquire; all others
+    // open with an agent-scope one (tools/microbench/hsa/stale.cpp: no stale word after any such write even without -- kept as the rule)
+    std::atomic<uint64_t> foreign_writes{1};
     uint32_t split_rank = 0, split_world = 1;
     uint32_t profiling = 0;                  // MIRHI_PROFILE_* bits
     std::mutex mu;
@@ -387,6 +394,7 @@ struct Workspace {
     // an unchanged frame uploads nothing, a changed one costs a memcpy, and no copy command ever enters a stream.  `pshadow` is the
     // host's copy of what the block holds (device memory is never read back over the BAR).
     uint8_t* pblock = nullptr; size_t pblock_bytes = 0; bool pblock_direct = false;   // direct: host-writable; else uploads go through `pstage`
+    bool foreign = false;                                                             // the block went up through a copy engine (fallback): the next scope acquires at system scope
     uint8_t* pstage = nullptr; size_t pstage_bytes = 0;                                // pinned staging for the fallback (hipMemcpyAsync on the lane)
     std::vector<uint8_t> pshadow, pimage;                                              // what the block holds / what it should hold
     size_t draws_off = 0, jobs_off = 0, draws_count = 0;
@@ -704,6 +712,7 @@ extern "C" mirhi_result mirhi_buffer_write(mirhi_buffer* buf, uint64_t offset, c
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer memory is not mapped");              // buffer.rs:266-268
     { mirhi_result r0 = sync_all_lanes(buf->dev); if (r0 != MIRHI_OK) return r0; }
     // host-coherent write semantics: ordered after previously submitted work, visible to later submits
+    buf->dev->foreign_writes++;
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
     HIP_TRY(hipStreamSynchronize(buf->dev->stream));
     return MIRHI_OK;
@@ -716,6 +725,7 @@ extern "C" mirhi_result mirhi_buffer_upload_via_staging(mirhi_buffer* buf, const
     if (len > buf->size)
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Upload exceeds buffer size: data %llu > buffer %llu", (unsigned long long)len, (unsigned long long)buf->size);
     { mirhi_result r0 = sync_all_lanes(buf->dev); if (r0 != MIRHI_OK) return r0; }
+    buf->dev->foreign_writes++;
     HIP_TRY(hipMemcpyAsync(buf->ptr, data, len, hipMemcpyHostToDevice, buf->dev->stream));
     HIP_TRY(hipStreamSynchronize(buf->dev->stream));
     return MIRHI_OK;
@@ -733,6 +743,7 @@ extern "C" mirhi_result mirhi_buffer_wrap_device_memory(mirhi_device* dev, mirhi
     if (size == 0 || !device_ptr) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer size must be greater than 0");
     mirhi_buffer* b = new (std::nothrow) mirhi_buffer{dev, usage, size, (uint8_t*)device_ptr, false};
     if (!b) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
+    dev->foreign_writes++;
     dev->children++;
     *out = b;
     return MIRHI_OK;
@@ -788,6 +799,7 @@ static mirhi_result image_common(mirhi_device* dev, uint32_t w, uint32_t h, mirh
 extern "C" mirhi_result mirhi_image_create(mirhi_device* dev, uint32_t w, uint32_t h, mirhi_format f, mirhi_image** out) { return image_common(dev, w, h, f, nullptr, out); }
 extern "C" mirhi_result mirhi_image_wrap_device_memory(mirhi_device* dev, uint32_t w, uint32_t h, mirhi_format f, void* ptr, mirhi_image** out) {
     if (!ptr) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: device_ptr is null");
+    if (dev) dev->foreign_writes++;
     return image_common(dev, w, h, f, ptr, out);
 }
 extern "C" uint32_t mirhi_image_width(const mirhi_image* img) { return img ? img->width : 0; }
@@ -800,6 +812,7 @@ extern "C" mirhi_result mirhi_image_upload(mirhi_image* img, const void* src, ui
     if (len != mirhi_image_size_bytes(img))
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: image upload size %llu != image size %llu", (unsigned long long)len, (unsigned long long)mirhi_image_size_bytes(img));
     { mirhi_result r0 = sync_all_lanes(img->dev); if (r0 != MIRHI_OK) return r0; }
+    img->dev->foreign_writes++;
     HIP_TRY(hipMemcpyAsync(img->ptr, src, len, hipMemcpyHostToDevice, img->dev->stream));
     HIP_TRY(hipStreamSynchronize(img->dev->stream));
     return MIRHI_OK;
@@ -842,6 +855,7 @@ extern "C" mirhi_result mirhi_image_generate_mips(mirhi_image* img) {
         hipError_t e = hipMalloc(&p, texels * 4);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc for a %zu-texel mip chain: %s", texels, hipGetErrorString(e)); }
         chain = (uint8_t*)p;
+        img->dev->foreign_writes++;
         HIP_TRY(hipMemcpyAsync(chain, img->ptr, (size_t)img->width * img->height * 4, hipMemcpyDeviceToDevice, img->dev->stream));
     }
     uint32_t sw = img->width, sh = img->height;
@@ -1580,6 +1594,7 @@ static mirhi_result pblock_commit(Workspace& w, hipStream_t stream) {
         } else {
             memcpy(w.pstage, w.pimage.data(), n);
             HIP_TRY(hipMemcpyAsync(w.pblock, w.pstage, n, hipMemcpyHostToDevice, stream));
+            w.foreign = true;
         }
     }
     w.pshadow = w.pimage;
@@ -1691,6 +1706,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     if (w.dirty) {
         HIP_TRY(hipMemsetAsync(w.bin_table, 0xFF, w.bin_table_bytes, stream));          // PAGE_EMPTY
         HIP_TRY(hipMemsetAsync(w.counters, 0, w.counters_words * 4, stream));
+        dev->foreign_writes++;
         w.parity = 0;
         w.dirty = false;
         cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true;      // (a submit on another stream or queue waits for the clears)
@@ -1909,6 +1925,7 @@ static mirhi_result stats_params_for(mirhi_cmd* c) {
             copies.push_back(P);
         }
     if (!copies.empty()) {
+        c->dev->foreign_writes++;
         HIP_TRY(hipMemcpyAsync(w.stats_params, copies.data(), copies.size() * sizeof(PassParams), hipMemcpyHostToDevice, c->dev->stream));
         HIP_TRY(hipStreamSynchronize(c->dev->stream));
     }
@@ -2155,9 +2172,14 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             if (use_native) {
                 tv.native = nq; tg.native = nq; tr.native = nq;
                 // the scope's first kernels see what the host wrote (parameter block, buffers uploaded since); its raster kernel publishes the frame
-                const bool sys = getenv("MIRHI_NATIVE_SYSTEM_SCOPE") != nullptr;          // (A/B runs: system scope on every packet)
-                tv.native_flags = NATIVE_ACQUIRE_SYSTEM | (sys ? NATIVE_RELEASE_SYSTEM : 0u);
-                tg.native_flags = ((P.vs_total_slots == 0u || sys) ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);      // (behind a vertex kernel: that one took the acquire)
+                // -- when something other than this library's kernels wrote device memory since this queue last acquired at system scope
+                static const int scope_mode = getenv("MIRHI_NATIVE_SYSTEM_SCOPE") ? atoi(getenv("MIRHI_NATIVE_SYSTEM_SCOPE")) : 0;   // 1: system scope on every packet, 2: on every scope's first (A/B runs)
+                const bool sys = scope_mode == 1;
+                const uint64_t foreign = dev->foreign_writes.load(std::memory_order_acquire);
+                const bool head_sys = sys || scope_mode == 2 || nq->seen_foreign != foreign || c->ws.foreign;
+                nq->seen_foreign = foreign; c->ws.foreign = false;
+                tv.native_flags = (head_sys ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);
+                tg.native_flags = (((P.vs_total_slots == 0u && head_sys) || sys) ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);      // (behind a vertex kernel: that one took the acquire)
                 tr.native_flags = NATIVE_RELEASE_SYSTEM | (sys ? NATIVE_ACQUIRE_SYSTEM : 0u);
             }
             // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
@@ -2615,6 +2637,7 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
     if (after && after->last_native) for (NativeQueue* nq : dev->native_lanes) if (nq == after->last_native) native_queue_drain(nq);     // (frames of a split go through HIP; one rendered before the split was set may not have)
     hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
     hipStream_t stream = comm->stream;
+    dev->foreign_writes++;                                   // (peers write the other bands into this frame)
     const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;
     const size_t row_bytes = (size_t)frame->width * format_bpp(frame->format);
     Rccl* R = comm->rccl;
