@@ -464,10 +464,10 @@ def main():
                                         "frames": nb * 8, "us_per_frame": round(1e6 * d1 / (nb * 8), 4)}
         except Exception as e:
             extras["batched_submit"] = {"error": repr(e)}
-    def rerecorded(rig_, fif, frames_, vary=0, phases=False):
+    def rerecorded(rig_, fif, frames_, vary=0, phases=False, uniform=None):
         """the reference-shaped loop (wait fence -> reset -> re-record -> end -> submit with fence) on `rig_`'s device, natively"""
         from renderer_rs_amd import frameloop
-        loop = frameloop.FrameLoop(rig_.dev, rig_.slots[0], rig_.swapchain(fif + 1), frames_in_flight=fif, vary_triangles=vary)
+        loop = frameloop.FrameLoop(rig_.dev, rig_.slots[0], rig_.swapchain(fif + 1), frames_in_flight=fif, vary_triangles=vary, per_frame_uniform=uniform)
         try:
             loop.run(max(32, frames_ // 4))
             sec = min(loop.run(frames_) for _ in range(2))
@@ -543,6 +543,8 @@ def main():
                 nfr = int(max(64, min(4096, 0.3e6 / max(1.0, us_guess))))
                 res_o = resubmitted(orig, orig.slots, nfr)
                 rer_o = rerecorded(orig, nfif, nfr)
+                # ... and with the frame's own object block rewritten first (Buffer::write_data, buffer.rs:247-279; one block per frame in flight)
+                rer_u = rerecorded(orig, nfif, nfr, uniform=int(m.Slot.OBJECT)) if orig.slots[0].draw_state[0]["object"] is not None else None
                 dev.wait_idle(); dev.reset_kernel_times(); dev.set_profiling(m.Profile.TIMING)
                 for _ in range(32):
                     orig.slots[0].render()
@@ -556,7 +558,8 @@ def main():
                 fus = k_us["raster"] + k_us["geometry"] + k_us["vertex"]
                 wl_out[other] = {"workload": f"{other}: {odesc}", "triangles": osc.num_triangles, "width": osc.width, "height": osc.height,
                                  "value": res_o["value"], "unit": "Mtris/s", "us_per_frame": res_o["us_per_frame"], "frames": nfr, "frames_in_flight": nfif,
-                                 "rerecorded_submit": {"value": rer_o["value"], "us_per_frame": rer_o["us_per_frame"]},
+                                 "rerecorded_submit": {"value": rer_o["value"], "us_per_frame": rer_o["us_per_frame"],
+                                                       "uniform_write_per_frame": {"value": rer_u["value"], "us_per_frame": rer_u["us_per_frame"]} if rer_u else None},
                                  "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": otraffic["frame_hbm_bytes"] if otraffic else None,
                                               "traffic_source": onote, "algorithmic_bytes_per_launch": oalg, "avg_kernel_us": round(k_us["raster"], 3),

@@ -44,6 +44,11 @@ typedef struct {
      * triangle count changes from frame to frame -- the re-recorded command buffer then has another shape every time */
     uint32_t vary_triangles;
     uint32_t submit_thread;               /* 1: mirhi_device_set_submit_thread(dev, 1) while the loop exists (the device's previous setting is restored at destroy) */
+    /* s + 1: uniform slot s of draw 0 gets one buffer PER FRAME IN FLIGHT (copies of the caller's, made at create), and every frame
+     * rewrites its slot's copy before recording -- Buffer::write_data (crates/rhi/src/buffer.rs:247-279) on the frame's own uniform
+     * buffer, the per-frame update of a camera / object block.  0: the caller's buffers are bound as they are, nothing is written */
+    uint32_t per_frame_uniform;
+    uint32_t reserved;
 } mirhost_frame_desc;
 
 typedef struct mirhost_frame_loop mirhost_frame_loop;

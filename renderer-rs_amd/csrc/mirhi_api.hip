@@ -340,6 +340,7 @@ struct mirhi_buffer {
     uint64_t size;
     uint8_t* ptr;
     bool owned;
+    bool host_direct = false;   // fine-grained device memory the host stores into (uniform buffers): write_data is a memcpy, as in the reference
 };
 
 struct mirhi_image {
@@ -693,14 +694,32 @@ extern "C" mirhi_result mirhi_buffer_create(mirhi_device* dev, mirhi_buffer_usag
     if (size == 0) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer size must be greater than 0");   // buffer.rs:150-154
     HIP_TRY(hipSetDevice(dev->ordinal));
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (size + 255) & ~(uint64_t)255);
+    // Uniform buffers are what a frame loop rewrites every frame (Buffer::write_data on mapped memory, buffer.rs:247-279): like the
+    // parameter block they live in fine-grained device memory that the host writes with plain stores (0.2 us per KB, no HIP call).
+    // MIRHI_PARAM_UPLOAD=copy (or a refused allocation) keeps them in plain device memory behind copies.
+    static const bool want_copy = [] { const char* v = getenv("MIRHI_PARAM_UPLOAD"); return v && strcmp(v, "copy") == 0; }();
+    bool direct = false;
+    hipError_t e = hipErrorNotSupported;
+    if (usage == MIRHI_BUFFER_UNIFORM && size <= (1u << 20) && !want_copy) {
+        e = hipExtMallocWithFlags(&p, (size + 255) & ~(uint64_t)255, hipDeviceMallocFinegrained);
+        direct = e == hipSuccess;
+        if (!direct) (void)hipGetLastError();
+    }
+    if (!direct) e = hipMalloc(&p, (size + 255) & ~(uint64_t)255);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: hipMalloc(%llu) for %s buffer: %s", (unsigned long long)size, usage_name(usage), hipGetErrorString(e)); }
     mirhi_buffer* b = new (std::nothrow) mirhi_buffer{dev, usage, size, (uint8_t*)p, true};
     if (!b) { (void)hipFree(p); return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed"); }
+    b->host_direct = direct;
     dev->children++;
     *out = b;
     return MIRHI_OK;
 }
+// Waits for the submissions that may still READ `buf` -- and for no others: the command buffers whose recording names memory inside the
+// buffer and that are pending.  (In the reference the memory is mapped and write_data is a memcpy: not writing what a frame in flight
+// reads is the caller's business, which is why it keeps one uniform buffer per frame in flight.  A frame loop that has waited for its
+// slot's fence finds nothing pending here; a caller that has not is made to wait for exactly the frames concerned.)
+static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit = false);
+static mirhi_result settle_readers(mirhi_device* dev, const uint8_t* lo, const uint8_t* hi);
 extern "C" mirhi_result mirhi_buffer_write(mirhi_buffer* buf, uint64_t offset, const void* data, uint64_t len) {
     NULL_CHECK(buf, "buffer");
     if (len == 0) return MIRHI_OK;                                                        // buffer.rs:248-250
@@ -710,8 +729,14 @@ extern "C" mirhi_result mirhi_buffer_write(mirhi_buffer* buf, uint64_t offset, c
                     (unsigned long long)offset, (unsigned long long)len, (unsigned long long)buf->size);   // buffer.rs:252-260
     if (!usage_host_visible(buf->usage))
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: Buffer memory is not mapped");              // buffer.rs:266-268
-    { mirhi_result r0 = sync_all_lanes(buf->dev); if (r0 != MIRHI_OK) return r0; }
-    // host-coherent write semantics: ordered after previously submitted work, visible to later submits
+    // host-coherent write semantics: ordered after the submitted work that reads the buffer, visible to later submits
+    { mirhi_result r0 = settle_readers(buf->dev, buf->ptr, buf->ptr + buf->size); if (r0 != MIRHI_OK) return r0; }
+    if (buf->host_direct) {
+        memcpy(buf->ptr + offset, data, len);           // write-combined stores over the BAR ...
+        __builtin_ia32_sfence();                          // ... out of the write-combining buffers before a later submit rings a doorbell
+        return MIRHI_OK;
+    }
+    HIP_TRY(hipSetDevice(buf->dev->ordinal));
     buf->dev->foreign_writes++;
     HIP_TRY(hipMemcpyAsync(buf->ptr + offset, data, len, hipMemcpyHostToDevice, buf->dev->stream));
     HIP_TRY(hipStreamSynchronize(buf->dev->stream));
@@ -1520,7 +1545,7 @@ static bool same_recording(const std::vector<RecordedPass>& a, const std::vector
 
 // The workspace of a command buffer that may still be executing must not be touched: Vulkan forbids re-recording a pending command
 // buffer, this build waits for it.  A frame loop that waits on its in-flight fence first (renderer.rs:371-374) never waits here.
-static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit = false) {
+static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit) {
     // (submit thread on: not before its queued submissions have been issued -- unless this IS the submit thread, re-planning the job it holds)
     while (!in_submit && cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     if (!cmd->pending) return MIRHI_OK;
@@ -1532,6 +1557,25 @@ static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit = false) {
     for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
     if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
     cmd->pending = false;
+    return MIRHI_OK;
+}
+
+static bool recording_reads(const std::vector<RecordedPass>& passes, const uint8_t* lo, const uint8_t* hi) {
+    auto in = [&](const void* q) { return q && (const uint8_t*)q >= lo && (const uint8_t*)q < hi; };
+    for (const RecordedPass& pass : passes)
+        for (const DrawDesc& d : pass.draws) {
+            if (in(d.vb) || in(d.ib) || in(d.camera) || in(d.object) || in(d.lights) || in(d.material) || in(d.point_lights) || in(d.spot_lights)) return true;
+        }
+    return false;
+}
+static mirhi_result settle_readers(mirhi_device* dev, const uint8_t* lo, const uint8_t* hi) {
+    std::vector<mirhi_cmd*> readers;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        for (mirhi_cmd* c : dev->cmds)
+            if ((c->pending || c->queued.load(std::memory_order_acquire) > 0) && (recording_reads(c->planned, lo, hi) || recording_reads(c->passes, lo, hi))) readers.push_back(c);
+    }
+    for (mirhi_cmd* c : readers) { const mirhi_result r = settle_pending(c, false); if (r != MIRHI_OK) return r; }
     return MIRHI_OK;
 }
 

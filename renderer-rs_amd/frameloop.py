@@ -36,7 +36,8 @@ class HostDraw(C.Structure):          # mirhost_draw
 class FrameDesc(C.Structure):         # mirhost_frame_desc
     _fields_ = [("frames_in_flight", C.c_uint32), ("image_count", C.c_uint32), ("images", C.POINTER(C.c_void_p)), ("depth", C.c_void_p),
                 ("clear_color", C.c_float * 4), ("clear_depth", C.c_float), ("draw_count", C.c_uint32), ("draws", C.POINTER(HostDraw)),
-                ("vary_triangles", C.c_uint32), ("submit_thread", C.c_uint32)]
+                ("vary_triangles", C.c_uint32), ("submit_thread", C.c_uint32),
+                ("per_frame_uniform", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -79,7 +80,8 @@ class FrameLoop:
     """Renderer::render_frame in a native loop.  `resources`: a SceneResources (its pipelines / buffers / textures and draw list are
     what every frame records); `images`: the colour targets cycled as swapchain images (frames_in_flight + 1 in the reference)."""
 
-    def __init__(self, device, resources, images: Sequence, frames_in_flight: int = 2, depth=None, vary_triangles: int = 0, submit_thread: bool = False):
+    def __init__(self, device, resources, images: Sequence, frames_in_flight: int = 2, depth=None, vary_triangles: int = 0, submit_thread: bool = False,
+                 per_frame_uniform=None):
         from . import IndexType, Slot
         s = resources.scene
         n = len(resources.draw_state)
@@ -112,6 +114,7 @@ class FrameLoop:
         desc.draw_count, desc.draws = n, self._draws
         desc.vary_triangles = vary_triangles
         desc.submit_thread = int(submit_thread)
+        desc.per_frame_uniform = 0 if per_frame_uniform is None else int(per_frame_uniform) + 1     # a Slot: one copy per frame in flight, rewritten every frame
         h = C.c_void_p()
         _check(lib().mirhost_frame_loop_create(device.handle, C.byref(desc), C.byref(h)))
         self.handle, self.images = h, list(images)

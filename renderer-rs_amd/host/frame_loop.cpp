@@ -24,15 +24,30 @@ struct mirhost_frame_loop {
     std::vector<mirhost_draw> draws;
     uint64_t frame_number = 0;
     uint32_t last_image = 0;
+    // desc.per_frame_uniform: one copy of draw 0's uniform buffer per frame in flight, rewritten by its frame
+    std::vector<mirhi_buffer*> frame_uniforms;
+    std::vector<uint8_t> uniform_bytes;
 
     mirhost_frame_loop(mirhi_device* dev, const mirhost_frame_desc& d)
         : device(mirhi::Device::borrow(dev)), pool(device, 0), frames(device, pool, d.frames_in_flight), desc(d),
           images(d.images, d.images + d.image_count), draws(d.draws, d.draws + d.draw_count) {
         desc.images = images.data(); desc.draws = draws.data();
+        if (d.per_frame_uniform && !draws.empty()) {
+            const auto& u = draws[0].uniforms[d.per_frame_uniform - 1];
+            const uint64_t bytes = u.range ? u.range : mirhi_buffer_size(u.buffer) - u.offset;
+            uniform_bytes.resize(bytes);
+            mirhi::check(mirhi_buffer_read(u.buffer, u.offset, uniform_bytes.data(), bytes));
+            for (uint32_t k = 0; k < d.frames_in_flight; k++) {
+                mirhi_buffer* b = nullptr;
+                mirhi::check(mirhi_buffer_create_with_data(dev, MIRHI_BUFFER_UNIFORM, uniform_bytes.data(), bytes, &b));
+                frame_uniforms.push_back(b);
+            }
+        }
     }
+    ~mirhost_frame_loop() { for (mirhi_buffer* b : frame_uniforms) (void)mirhi_buffer_destroy(b); }
 
     // renderer.rs:452-557
-    void record_commands(const mirhi::CommandBuffer& cmd, uint32_t image_index) const {
+    void record_commands(const mirhi::CommandBuffer& cmd, uint32_t image_index, uint32_t slot) const {
         mirhi_rendering_info info;
         mirhi_rendering_info_default(&info);
         info.color_image = images[image_index];                            // :479-488 ColorAttachment, CLEAR / STORE
@@ -48,8 +63,13 @@ struct mirhost_frame_loop {
             mirhi::check(mirhi_cmd_bind_pipeline(h, d.pipeline));           // :521-527
             mirhi_buffer* vbs[1] = {d.vertex_buffer}; const uint64_t offs[1] = {d.vertex_offset_bytes};
             mirhi::check(mirhi_cmd_bind_vertex_buffers(h, 0, 1, vbs, offs));   // :530-534
-            for (int s = 0; s < MIRHI_SLOT_COUNT; s++)
-                if (d.uniforms[s].buffer) mirhi::check(mirhi_cmd_bind_uniform(h, (mirhi_uniform_slot)s, d.uniforms[s].buffer, d.uniforms[s].offset, d.uniforms[s].range));
+            for (int s = 0; s < MIRHI_SLOT_COUNT; s++) {
+                if (!d.uniforms[s].buffer) continue;
+                if (di == 0 && !frame_uniforms.empty() && (uint32_t)s + 1 == desc.per_frame_uniform)
+                    mirhi::check(mirhi_cmd_bind_uniform(h, (mirhi_uniform_slot)s, frame_uniforms[slot], 0, uniform_bytes.size()));
+                else
+                    mirhi::check(mirhi_cmd_bind_uniform(h, (mirhi_uniform_slot)s, d.uniforms[s].buffer, d.uniforms[s].offset, d.uniforms[s].range));
+            }
             for (int t = 0; t < MIRHI_TEXTURE_COUNT; t++)
                 if (d.textures[t] || t < 2) mirhi::check(mirhi_cmd_bind_texture(h, (mirhi_texture_slot)t, d.textures[t]));
             uint32_t count = d.count;
@@ -79,8 +99,11 @@ struct mirhost_frame_loop {
         frames.wait_for_frame();                                            // :371-374  wait_for_fence(in_flight_fences[current_frame])
         const double t1 = timed ? now() : 0.0;
         frames.acquire_next_image((uint32_t)images.size());                 // :377-390
+        const uint32_t slot = (uint32_t)frames.current_frame_index();
+        if (!frame_uniforms.empty())                                        // this frame's uniform block: its previous frame has been waited for above
+            mirhi::check(mirhi_buffer_write(frame_uniforms[slot], 0, uniform_bytes.data(), uniform_bytes.size()));
         frames.begin_frame();                                               // :393-397  reset_fence; :457-467 command_buffer.reset(), begin()
-        record_commands(frames.current_frame().command_buffer, frames.image_index());
+        record_commands(frames.current_frame().command_buffer, frames.image_index(), slot);
         const double t2 = timed ? now() : 0.0;
         frames.end_frame();                                                 // :555 command_buffer.end()
         const double t3 = timed ? now() : 0.0;
@@ -100,6 +123,8 @@ extern "C" mirhi_result mirhost_frame_loop_create(mirhi_device* dev, const mirho
     *out = nullptr;
     if (desc->frames_in_flight == 0 || desc->frames_in_flight > 16 || desc->image_count == 0 || !desc->images || (desc->draw_count && !desc->draws))
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: frame description needs 1..16 frames in flight, at least one image, and its draws");
+    if (desc->per_frame_uniform > MIRHI_SLOT_COUNT || (desc->per_frame_uniform && (!desc->draw_count || !desc->draws[0].uniforms[desc->per_frame_uniform - 1].buffer)))
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: per_frame_uniform names a slot draw 0 does not bind");
     for (uint32_t i = 0; i < desc->image_count; i++) if (!desc->images[i]) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: images[i] is null");
     for (uint32_t i = 0; i < desc->draw_count; i++)
         if (!desc->draws[i].pipeline || !desc->draws[i].vertex_buffer) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: a draw needs a pipeline and a vertex buffer");

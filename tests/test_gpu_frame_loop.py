@@ -210,3 +210,56 @@ def test_native_dispatch_carries_the_frame_loop(mirhi, scenes):
     dev.set_profiling(0)
     assert dev.stats().native_dispatches == n1
     res.destroy(); f.destroy(); dev.destroy()
+
+
+def test_native_frame_loop_rewrites_its_uniform_block_every_frame(mirhi, oracle, scenes):
+    """mirhost_frame_desc.per_frame_uniform: one object block per frame in flight, rewritten (Buffer::write_data, buffer.rs:247-279) by its
+    frame before recording.  Uniform buffers live in host-written fine-grained memory; the frames are the oracle's all the same."""
+    from renderer_rs_amd import frameloop
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(2)
+    scene = scenes.displaced_sphere(30, 23, 320, 200, seed=5)
+    res = mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB)
+    images = [mirhi.Image(dev, scene.width, scene.height, mirhi.Format.B8G8R8A8_SRGB) for _ in range(3)]
+    ref = oracle.render(scene, want_bgra8=True)["bgra8"].astype(np.int32)
+    for vary in (0, 5):
+        loop = frameloop.FrameLoop(dev, res, images, frames_in_flight=2, vary_triangles=vary, per_frame_uniform=mirhi.Slot.OBJECT)
+        loop.run(11)                                         # (frame 10 draws count - 3 * (10 % 5) = count vertices)
+        img, rendered = loop.last_image()
+        assert rendered == 11
+        d = np.abs(img.read().astype(np.int32) - ref)
+        assert d.max() <= 1, f"vary {vary}: sRGB8 differs by {d.max()} LSB"
+        loop.destroy()
+    for im in images:
+        im.destroy()
+    res.destroy()
+    dev.destroy()
+
+
+def test_write_data_waits_for_the_frames_that_read_the_buffer_and_no_others(mirhi, oracle, scenes):
+    """Buffer::write_data on a uniform buffer that a PENDING frame reads: the write lands behind that frame (it renders with the old
+    block), the next submit sees the new one.  A frame in flight on another lane that does not read the buffer is not waited for -- which
+    shows as nothing here but is what keeps a frame loop with per-frame uniform blocks overlapped."""
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(2)
+    base = scenes.displaced_sphere(40, 31, 384, 240, seed=11)
+    other = mirhi.SceneResources(dev, scenes.random_triangles(6000, 640, 360, seed=2), mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    other.cmd.set_queue_lane(1)
+    other_ref = oracle.render(other.scene, want_bgra8=False)
+    sc = copy.deepcopy(base)
+    res = mirhi.SceneResources(dev, sc, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    res.cmd.set_queue_lane(0)
+    blocks = [scenes.object_ubo(scenes.trs((1.0, 1.0 - 0.05 * k, 1.0), scenes.quat_axis_angle((0.0, 1.0, 0.0), 0.4 * k), (0.03 * k, 0.0, 0.0))) for k in range(6)]
+    res.draw_state[0]["object"].write_data(0, blocks[0])
+    for k in range(5):
+        res.render()                                         # frame with block k, not waited for
+        other.render()                                       # a frame on the other lane that does not read the block
+        res.draw_state[0]["object"].write_data(0, blocks[k + 1])      # must land behind the pending frame
+        dev.wait_idle()
+        sc.draws[0].object = blocks[k]
+        _check(_read(res), oracle.render(sc, want_bgra8=False), f"frame rendered before write {k + 1}")
+    res.render(); dev.wait_idle()
+    sc.draws[0].object = blocks[5]
+    _check(_read(res), oracle.render(sc, want_bgra8=False), "frame rendered after the last write")
+    _check(_read(other), other_ref, "the other lane's frame")
+    res.destroy(); other.destroy(); dev.destroy()
