@@ -480,7 +480,10 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
                                             uint32_t lane) {
     // Most bins hold fewer than 64 records, so one wave builds all tile records of a tile.  Which wave does it rotates
     // with the tile: wave k of every workgroup sits on the same SIMD, and a fixed choice would load that SIMD alone.
-    const uint32_t ftid = (tid + 64u * ((tx + ty) & (uint32_t)(WPT - 1))) & ((uint32_t)WPT * 64u - 1u);
+    // (fq, the wave's place in the staging order, is wave-uniform: a wave none of whose lanes has a record to build -- three of the four
+    // when the bin holds fewer than 64 -- branches over the whole staging step on the scalar unit instead of walking it with no lane active)
+    const uint32_t fq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((tid >> 6) + ((tx + ty) & (uint32_t)(WPT - 1))) & (uint32_t)(WPT - 1)));
+    const uint32_t ftid = fq * 64u + lane;
     for (uint32_t base0 = 0; base0 < n_total; base0 += (uint32_t)CHUNK * (TEAMS > 1 ? nteams : 1u)) {
         const uint32_t base = base0 + team * (uint32_t)CHUNK;
         // Two staging counters used alternately: the one of this pass was zeroed during the previous pass (or at kernel
@@ -497,6 +500,8 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         const uint32_t i = base + ftid;
         bool hit = false;
         uint4 rec[4]; uint32_t box = 0;
+        const bool wave_stages = fq * 64u < (uint32_t)CHUNK && base + fq * 64u < n_total;      // (scalar)
+        if (wave_stages) {
         if (ftid < (uint32_t)CHUNK && i < n_total) {
             TileTri T;
             if (BINS) {
@@ -579,6 +584,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
             if (!TP) lds_box[slot] = box;
         }
+        }   // wave_stages
         __syncthreads();
         const uint32_t n = *cnt;
         flip ^= 1u;
