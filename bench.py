@@ -472,7 +472,7 @@ def main():
             loop.run(max(32, frames_ // 4))
             sec = min(loop.run(frames_) for _ in range(2))
             out_ = {"value": round(rig_.scene.num_triangles * frames_ / sec / 1e6, 3), "unit": "Mtris/s", "us_per_frame": round(1e6 * sec / frames_, 4),
-                    "frames_in_flight": fif, "frames": frames_}
+                    "frames_in_flight": fif, "fence_gated": True, "frames": frames_}
             if phases:
                 loop.phase_seconds(True)
                 loop.run(frames_)
@@ -492,7 +492,8 @@ def main():
         rig_.dev.wait_idle()
         d1 = time.perf_counter() - t1
         return {"value": round(rig_.scene.num_triangles * frames_ / d1 / 1e6, 3), "unit": "Mtris/s", "us_per_frame": round(1e6 * d1 / frames_, 4),
-                "frames_in_flight": len(slots_), "frames": frames_}
+                "command_buffers": len(slots_), "queue_lanes": len(slots_), "fence_gated": False, "frames": frames_,
+                "note": "recorded once, resubmitted round-robin without waiting on fences (the lanes queue up)"}
 
     if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
         try:
