@@ -258,7 +258,8 @@ def lib():
             _build.build()
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension must be built (python __graft_entry__.py)")
-        L = C.CDLL(LIB_PATH)
+        # (a variant build named by MIRHI_LIB_NAME is loaded globally, so that libmirhost.so -- linked against libmirhi.so -- binds to IT)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if os.environ.get("MIRHI_LIB_NAME") else C.DEFAULT_MODE)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args

@@ -61,8 +61,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    if out == LIB:
-        extract_code_object(objs[0], HSACO, verbose)
+    extract_code_object(objs[0], out[:-3] + "_kernels.hsaco", verbose)      # (libmirhi.so -> libmirhi_kernels.hsaco: what the native dispatcher of THAT library loads)
     return out
 
 
@@ -94,6 +93,10 @@ def build_stamps(verbose: bool = False) -> str:
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         print(build_stamps(verbose=True))
+        sys.exit(0)
+    if "--variant" in sys.argv:          # build.py --variant NAME -DX=1 ...: libmirhi_NAME.so (+ its code object) beside the product, for tools/ab_bench.sh
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build(force=True, verbose=True, extra_flags=[a for a in sys.argv if a.startswith("-D")], out=os.path.join(HERE, f"libmirhi_{name}.so"), suffix="." + name))
         sys.exit(0)
     build(force="--force" in sys.argv, verbose=True,
           extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else ())

@@ -126,12 +126,15 @@ hsa_status_t native_pick_agent(hsa_agent_t a, void* data) {
 }
 
 // the directory this shared library was loaded from (the code object sits beside it)
-std::string native_library_dir() {
+// <dir>/<library name without .so>_kernels.hsaco: the code object build.py took out of THIS library's object (libmirhi.so -> libmirhi_kernels.hsaco; a
+// variant build beside it -- tools/ab_bench.sh -- finds its own)
+std::string native_code_object_path() {
     Dl_info info;
-    if (!dladdr(reinterpret_cast<const void*>(&native_library_dir), &info) || !info.dli_fname) return ".";
+    if (!dladdr(reinterpret_cast<const void*>(&native_code_object_path), &info) || !info.dli_fname) return "./libmirhi_kernels.hsaco";
     std::string p = info.dli_fname;
-    const size_t slash = p.find_last_of('/');
-    return slash == std::string::npos ? "." : p.substr(0, slash);
+    const size_t dot = p.rfind(".so");
+    if (dot != std::string::npos) p.erase(dot);
+    return p + "_kernels.hsaco";
 }
 
 mirhi::NativeDevice* native_device_open(int ordinal) {
@@ -148,7 +151,7 @@ mirhi::NativeDevice* native_device_open(int ordinal) {
     std::pair<uint32_t, hsa_agent_t*> want{(uint32_t)((bus << 8) | (devid << 3)), &nd->agent};
     (void)hsa_iterate_agents(native_pick_agent, &want);
     if (nd->agent.handle == 0) return fail_with("no ROCr agent with the HIP device's PCI id");
-    const std::string path = native_library_dir() + "/libmirhi_kernels.hsaco";
+    const std::string path = native_code_object_path();
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return fail_with(path + " is missing (build.py writes it)");
     std::vector<char> blob;
@@ -157,7 +160,7 @@ mirhi::NativeDevice* native_device_open(int ordinal) {
     hsa_code_object_reader_t reader;
     if (hsa_code_object_reader_create_from_memory(blob.data(), blob.size(), &reader) != HSA_STATUS_SUCCESS) return fail_with("code object reader");
     if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &nd->exe) != HSA_STATUS_SUCCESS) return fail_with("executable create");
-    if (hsa_executable_load_agent_code_object(nd->exe, nd->agent, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return fail_with("code object load (is libmirhi_kernels.hsaco of this build?)");
+    if (hsa_executable_load_agent_code_object(nd->exe, nd->agent, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return fail_with("code object load (is " + path + " of this build?)");
     if (hsa_executable_freeze(nd->exe, nullptr) != HSA_STATUS_SUCCESS) return fail_with("executable freeze");
     nd->ok = true;
     return nd;

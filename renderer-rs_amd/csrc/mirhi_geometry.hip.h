@@ -3,6 +3,12 @@
 #ifndef MIRHI_GEOMETRY_HIP_H
 #define MIRHI_GEOMETRY_HIP_H
 
+// Issue priority of the vertex / geometry kernels' waves (s_setprio): these kernels are a few latency-bound waves whose dependent chain is the
+// frame's critical path; in a frame loop they share their SIMDs with other frames' raster waves, which are throughput work.
+#ifndef MIRHI_GEOM_PRIO
+#define MIRHI_GEOM_PRIO 0
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // a1/a2/a4: index fetch, vertex fetch, vertex-shader position
 // ------------------------------------------------------------------------------------------------
@@ -214,6 +220,7 @@ __device__ __forceinline__ uint32_t find_draw(ParamsRef P, uint32_t prim) {
 // a4: vertex-shader pre-pass for the MODEL / MODEL_FULL programs (vertex/model.hlsl:39-68)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void vertex_body(const PassParams* __restrict__ params) {
+    if (MIRHI_GEOM_PRIO) __builtin_amdgcn_s_setprio(MIRHI_GEOM_PRIO);
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     if (slot0 >= P.vs_total_slots) return;              // (batched launch: the grid is sized for the largest scope)
@@ -492,6 +499,7 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     f4 (*poly)[2][CLIP_MAX_VERTS] = reinterpret_cast<f4 (*)[2][CLIP_MAX_VERTS]>(&lds_tri[0][0]);
     __shared__ uint32_t lds_meta[GEOM_THREADS];
     __shared__ uint16_t lds_owner[PAIR_MAX];
+    if (MIRHI_GEOM_PRIO) __builtin_amdgcn_s_setprio(MIRHI_GEOM_PRIO);
     GSTAMP(0);
     const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
     uint32_t lo = 0, hi = H.num_draws;

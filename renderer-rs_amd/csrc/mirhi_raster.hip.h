@@ -5,6 +5,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef MIRHI_STAGE_PRIO
+#define MIRHI_STAGE_PRIO 0
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // raster kernel
 // ------------------------------------------------------------------------------------------------
@@ -502,6 +506,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
         uint4 rec[4]; uint32_t box = 0;
         const bool wave_stages = fq * 64u < (uint32_t)CHUNK && base + fq * 64u < n_total;      // (scalar)
         if (wave_stages) {
+        if (MIRHI_STAGE_PRIO) __builtin_amdgcn_s_setprio(MIRHI_STAGE_PRIO);      // (the tile's other waves wait at the barrier for this one)
         if (ftid < (uint32_t)CHUNK && i < n_total) {
             TileTri T;
             if (BINS) {
@@ -584,6 +589,7 @@ __device__ __forceinline__ void raster_list(const uint4* __restrict__ list, uint
             lds_rec[slot * 4u + 2] = rec[2]; lds_rec[slot * 4u + 3] = rec[3];
             if (!TP) lds_box[slot] = box;
         }
+        if (MIRHI_STAGE_PRIO) __builtin_amdgcn_s_setprio(0);
         }   // wave_stages
         __syncthreads();
         const uint32_t n = *cnt;
