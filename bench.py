@@ -563,6 +563,7 @@ def main():
                                                        "uniform_write_per_frame": {"value": rer_u["value"], "us_per_frame": rer_u["us_per_frame"]} if rer_u else None},
                                  "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": otraffic["frame_hbm_bytes"] if otraffic else None,
+                                              "traffic_structural": otraffic.get("structural_bytes") if otraffic else None,
                                               "traffic_source": onote, "algorithmic_bytes_per_launch": oalg, "avg_kernel_us": round(k_us["raster"], 3),
                                               "geometry_kernel_us": round(k_us["geometry"], 3), "vertex_kernel_us": round(k_us["vertex"], 3),
                                               "frame_frac": round(oalg / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if fus > 0 else None}}
@@ -634,6 +635,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "raster_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic["frame_hbm_bytes"] if traffic else None, "traffic_scope": "whole frame: vertex + geometry + raster kernels",
+                         "traffic_structural": traffic.get("structural_bytes") if traffic else None,   # algorithmic bytes + the intermediate streams (shaded vertices, bin records) written once and read once
                          "traffic_source": traffic_note, "kernel_source_sha16": src_hash,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_us": round(ras_us, 3),
                          "geometry_kernel_us": round(geo_us, 3), "vertex_kernel_us": round(vs_us, 3),

@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence behind bench.py's lines into gpurun_out/prof_<tag>/ (run on the GPU box):
 #   stats/      rocprofv3 --kernel-trace --stats of the isolated pass (bench.py --profile-pass-only: one frame on the GPU at a time,
 #               every dispatch of the process isolated) -- the tracer's average durations must agree with roofline.avg_kernel_us
-#   pmc_*       separate PMC passes of the same command: SQ instruction mix, FETCH_SIZE, WRITE_SIZE (never combined with a trace domain
+#   pmc_*       separate PMC passes of the same command: SQ instruction mix, FETCH_SIZE, WRITE_SIZE, read requests by size (never combined with a trace domain
 #               other than --kernel-trace)
 #   trace/      rocprofv3 --kernel-trace of the driver's command (4 queue lanes in flight): per-dispatch begin / end
 #   bench_*     plain bench lines (no tool attached): the driver's command, and the other BASELINE configs
@@ -18,6 +18,8 @@ for w in c2 c3 c4 c5; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES --output-format csv -d $out/pmc_sq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_sq_$w.err
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_$w.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_write_$w.err
+  # the L2's read requests by size and in 32-byte units to DRAM (gfx950 counters): the exact byte count FETCH_SIZE's doubling is checked against
+  rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $out/pmc_rdreq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_rdreq_$w.err
   echo "collected $w"
 done
 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err

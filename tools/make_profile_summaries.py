@@ -41,7 +41,9 @@ for w in ("c2", "c3", "c4", "c5"):
     line = last_json(os.path.join(src, f"bench_profile_pass_{w}.json"))
     json.dump(line, open(os.path.join(dst, f"{tag}_{w}_bench_profile_pass.json"), "w"), indent=1)
     rows, per_kernel = [], collections.defaultdict(dict)
-    for pass_dir in (f"pmc_sq_{w}", f"pmc_fetch_{w}", f"pmc_write_{w}"):
+    for pass_dir in (f"pmc_sq_{w}", f"pmc_fetch_{w}", f"pmc_write_{w}", f"pmc_rdreq_{w}"):
+        if not glob.glob(os.path.join(src, pass_dir) + "/**/*counter_collection.csv", recursive=True):
+            continue
         for (kern, ctr), (n, mean) in sorted(means(pass_dir).items()):
             if "mirhi::" not in kern:
                 continue
@@ -54,18 +56,28 @@ for w in ("c2", "c3", "c4", "c5"):
         cw.writerows(rows)
     traffic = {"workload": w, "kernel_source_sha16": line["roofline"]["kernel_source_sha16"],
                "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --workload {w} --profile-pass-only",
-               "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide "
-                            "coalesced streams (MI355X_MICROARCH.md, HBM section), so the read side is doubled; that correction is calibrated "
-                            "for 16 B/lane streaming reads and is an upper bound for the record gathers here",
+               "unit_note": "FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B "
+                            "(MI355X_MICROARCH.md, HBM section), so the read side is doubled.  The guide calibrates that for 16 B/lane streaming reads; "
+                            "read_bytes_exact (the L2's read requests by size, TCC_EA0_RDREQ_{64B,128B}, and in 32-byte units to DRAM, "
+                            "TCC_EA0_RDREQ_DRAM_32B: a separate pass) shows it holds for these kernels' gathers as well: the L2 fetches whole 128-byte lines",
                "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"]}
     frame = 0
     for k, d in per_kernel.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             b = int(round((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024))
             traffic[k] = {"fetch_size_kb": round(d["FETCH_SIZE"], 2), "write_size_kb": round(d["WRITE_SIZE"], 2), "hbm_bytes_per_launch": b}
+            if "TCC_EA0_RDREQ_sum" in d:
+                n, n64, n128 = d["TCC_EA0_RDREQ_sum"], d.get("TCC_EA0_RDREQ_64B_sum", 0.0), d.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+                traffic[k]["read_bytes_exact"] = {"requests": round(n), "of_64B": round(n64), "of_128B": round(n128), "by_size": int(round(32 * (n - n64 - n128) + 64 * n64 + 128 * n128)),
+                                                  "dram_32B_units": int(round(32 * d.get("TCC_EA0_RDREQ_DRAM_32B_sum", 0.0))), "doubled_fetch_size": int(round(2048 * d["FETCH_SIZE"]))}
             frame += b
     traffic["frame_hbm_bytes"] = frame
     traffic["frame_over_algorithmic"] = round(frame / traffic["algorithmic_bytes"], 3)
+    # what a binned rasterizer moves by construction: the algorithmic bytes plus every intermediate stream written once and read once (shaded vertices: the
+    # vertex kernel's writes; bin records + flat colours: the geometry kernel's writes)
+    inter = sum(int(round(traffic[k]["write_size_kb"] * 1024)) for k in ("vertex_kernel", "geometry_kernel") if k in traffic)
+    traffic["structural_bytes"] = traffic["algorithmic_bytes"] + 2 * inter
+    traffic["frame_over_structural"] = round(frame / traffic["structural_bytes"], 3)
     json.dump(traffic, open(os.path.join(dst, f"{tag}_{w}_hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
