@@ -1576,7 +1576,9 @@ static mirhi_result settle_readers(mirhi_device* dev, const uint8_t* lo, const u
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         for (mirhi_cmd* c : dev->cmds)
-            if ((c->pending || c->queued.load(std::memory_order_acquire) > 0) && (recording_reads(c->planned, lo, hi) || recording_reads(c->passes, lo, hi))) readers.push_back(c);
+            // (`planned` is the recording the pending submissions were planned from and does not change while one is pending; `passes` may be
+            // under re-recording by another host thread at this very moment)
+            if ((c->pending || c->queued.load(std::memory_order_acquire) > 0) && recording_reads(c->planned, lo, hi)) readers.push_back(c);
     }
     for (mirhi_cmd* c : readers) { const mirhi_result r = settle_pending(c, false); if (r != MIRHI_OK) return r; }
     return MIRHI_OK;
@@ -1940,7 +1942,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     w.wide_eligible = any_wide_eligible;
     if ((r = pblock_commit(w, stream)) != MIRHI_OK) return r;
     if (!w.pblock_direct) { cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true; }     // (the copy is in the lane's stream)
-    cmd->planned = cmd->passes;
+    { std::lock_guard<std::mutex> lk(dev->mu); cmd->planned = cmd->passes; }      // (settle_readers scans `planned` of pending command buffers under this lock)
     cmd->plan_split_rank = dev->split_rank; cmd->plan_split_world = dev->split_world;
     cmd->plan_valid = true;
     dev->stats.workspace_bytes = w.bytes();

@@ -263,3 +263,52 @@ def test_write_data_waits_for_the_frames_that_read_the_buffer_and_no_others(mirh
     _check(_read(res), oracle.render(sc, want_bgra8=False), "frame rendered after the last write")
     _check(_read(other), other_ref, "the other lane's frame")
     res.destroy(); other.destroy(); dev.destroy()
+
+
+def test_write_data_from_one_thread_while_another_runs_the_frame_loop(mirhi, oracle, scenes):
+    """write_data looks through the device's pending command buffers for readers of the buffer while another host thread re-records and
+    submits its own (the native loop, every frame another triangle count so that every end() rebuilds its plan): both threads' frames are
+    the oracle's, nothing deadlocks, nothing is read while it changes."""
+    import threading
+    from renderer_rs_amd import frameloop
+    dev = mirhi.Device(0)
+    dev.set_queue_lanes(3)
+    loop_scene = scenes.random_triangles(3000, 640, 360, seed=21)
+    loop_res = mirhi.SceneResources(dev, loop_scene, mirhi.Format.B8G8R8A8_SRGB)
+    images = [mirhi.Image(dev, loop_scene.width, loop_scene.height, mirhi.Format.B8G8R8A8_SRGB) for _ in range(3)]
+    loop = frameloop.FrameLoop(dev, loop_res, images, frames_in_flight=2, vary_triangles=5)
+    base = scenes.displaced_sphere(24, 17, 256, 160, seed=3)
+    sc = copy.deepcopy(base)
+    res = mirhi.SceneResources(dev, sc, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    res.cmd.set_queue_lane(2)
+    errors = []
+
+    def run_loop():
+        try:
+            for _ in range(12):
+                loop.run(50)
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=run_loop)
+    t.start()
+    fence = mirhi.Fence(dev)
+    for k in range(40):
+        block = scenes.object_ubo(scenes.trs((1.0, 1.0 - 0.01 * k, 1.0), scenes.quat_axis_angle((0.0, 1.0, 0.0), 0.1 * k), (0.0, 0.0, 0.0)))
+        res.draw_state[0]["object"].write_data(0, block)
+        res.cmd.reset(); res.record()
+        res.render(fence); fence.wait(); fence.reset()
+    t.join()
+    assert not errors, errors
+    sc.draws[0].object = block
+    _check(_read(res), oracle.render(sc, want_bgra8=False), "the writing thread's last frame")
+    img, rendered = loop.last_image()
+    assert rendered == 600
+    lsc = copy.deepcopy(loop_scene)
+    lsc.draws[0].count -= 3 * ((rendered - 1) % 5)
+    d = np.abs(img.read().astype(np.int32) - oracle.render(lsc, want_bgra8=True)["bgra8"].astype(np.int32))
+    assert d.max() <= 1
+    loop.destroy(); fence.destroy()
+    for im in images:
+        im.destroy()
+    res.destroy(); loop_res.destroy(); dev.destroy()
