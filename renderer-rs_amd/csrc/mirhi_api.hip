@@ -700,7 +700,8 @@ extern "C" mirhi_result mirhi_buffer_create(mirhi_device* dev, mirhi_buffer_usag
     // Uniform buffers are what a frame loop rewrites every frame (Buffer::write_data on mapped memory, buffer.rs:247-279): like the
     // parameter block they live in fine-grained device memory that the host writes with plain stores (0.2 us per KB, no HIP call).
     // MIRHI_PARAM_UPLOAD=copy (or a refused allocation) keeps them in plain device memory behind copies.
-    static const bool want_copy = [] { const char* v = getenv("MIRHI_PARAM_UPLOAD"); return v && strcmp(v, "copy") == 0; }();
+    const char* upload = getenv("MIRHI_PARAM_UPLOAD");
+    const bool want_copy = upload && strcmp(upload, "copy") == 0;
     bool direct = false;
     hipError_t e = hipErrorNotSupported;
     if (usage == MIRHI_BUFFER_UNIFORM && size <= (1u << 20) && !want_copy) {

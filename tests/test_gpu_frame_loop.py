@@ -312,3 +312,31 @@ def test_write_data_from_one_thread_while_another_runs_the_frame_loop(mirhi, ora
     for im in images:
         im.destroy()
     res.destroy(); loop_res.destroy(); dev.destroy()
+
+
+@pytest.mark.parametrize("upload", ["direct", "copy"])
+def test_buffers_rewritten_between_frames_are_seen_by_the_next_frame(mirhi, oracle, scenes, monkeypatch, upload):
+    """Between two submits of one command buffer the host rewrites the vertex buffer (plain device memory behind a copy engine: the next
+    submit's first packet acquires at system scope, mirhi_device::foreign_writes) and the object block (host-written fine-grained memory,
+    or -- MIRHI_PARAM_UPLOAD=copy, the fallback -- plain memory behind copies, parameter block included).  Every frame is the oracle's frame
+    of what the buffers held when it was submitted."""
+    if upload == "copy":
+        monkeypatch.setenv("MIRHI_PARAM_UPLOAD", "copy")
+    dev = mirhi.Device(0)
+    base = scenes.displaced_sphere(36, 27, 384, 240, seed=7)
+    sc = copy.deepcopy(base)
+    res = mirhi.SceneResources(dev, sc, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    fence = mirhi.Fence(dev)
+    verts0 = np.array(base.draws[0].vertices, dtype=np.float32, copy=True)
+    for k in range(5):
+        v = verts0.copy()
+        v[:, 0:3] *= np.float32(1.0 - 0.06 * k)              # positions: another mesh every frame
+        sc.draws[0].vertices = v
+        sc.draws[0].object = scenes.object_ubo(scenes.trs((1.0, 1.0, 1.0), scenes.quat_axis_angle((0.0, 1.0, 0.0), 0.3 * k), (0.01 * k, 0.0, 0.0)))
+        res.draw_state[0]["vb"].write_data(0, v)
+        res.draw_state[0]["object"].write_data(0, sc.draws[0].object)
+        if k % 2:                                            # re-recorded or resubmitted as it is
+            res.cmd.reset(); res.record()
+        res.render(fence); fence.wait(); fence.reset()
+        _check(_read(res), oracle.render(sc, want_bgra8=False), f"{upload}: frame {k}")
+    res.destroy(); fence.destroy(); dev.destroy()
