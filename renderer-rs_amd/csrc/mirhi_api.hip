@@ -1523,6 +1523,7 @@ static RasterMode raster_mode(const RecordedPass& pass, size_t tiles, bool sprea
 // current plan was built from -- and again in front of a submit when an earlier submission exhausted the bin pool
 // (Workspace::grow_pool) or showed a spread-out mesh (Workspace::replan).
 static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit = false);
+static mirhi_result pblock_commit(Workspace& w, hipStream_t stream);
 
 static bool same_target(const RecordedPass::Target& a, const RecordedPass::Target& b) {
     return a.ptr == b.ptr && a.width == b.width && a.height == b.height && a.format == b.format;
@@ -1530,11 +1531,15 @@ static bool same_target(const RecordedPass::Target& a, const RecordedPass::Targe
 // Two recordings describe the same frame shape: same attachments, load / store ops, clear values, depth / blend state and, byte for
 // byte, the same draw descriptors (resolved device pointers, counts, viewport, scissor, state).  Buffer CONTENTS are not part of it:
 // the plan holds pointers, and a frame loop that rewrites its uniform buffer between frames records the same shape every time.
-static bool same_recording(const std::vector<RecordedPass>& a, const std::vector<RecordedPass>& b) {
+// any_color_address: the colour targets may sit at other addresses (same extent and format) -- the recording of a frame loop that cycles N + 1 swapchain images
+// through N command buffers (swapchain.rs:228-236, renderer.rs:377-390): everything the plan holds but PassParams::color is the same then
+static bool same_recording(const std::vector<RecordedPass>& a, const std::vector<RecordedPass>& b, bool any_color_address = false) {
     if (a.size() != b.size()) return false;
     for (size_t i = 0; i < a.size(); i++) {
         const RecordedPass& x = a[i]; const RecordedPass& y = b[i];
-        if (!same_target(x.color_t, y.color_t) || !same_target(x.depth_t, y.depth_t) || !same_target(x.prim_t, y.prim_t)) return false;
+        if (any_color_address ? (x.color_t.width != y.color_t.width || x.color_t.height != y.color_t.height || x.color_t.format != y.color_t.format || !x.color_t.ptr != !y.color_t.ptr)
+                              : !same_target(x.color_t, y.color_t)) return false;
+        if (!same_target(x.depth_t, y.depth_t) || !same_target(x.prim_t, y.prim_t)) return false;
         if (x.info.color_load_op != y.info.color_load_op || x.info.color_store_op != y.info.color_store_op || x.info.depth_load_op != y.info.depth_load_op ||
             x.info.depth_store_op != y.info.depth_store_op || memcmp(x.info.clear_color, y.info.clear_color, sizeof x.info.clear_color) != 0 ||
             memcmp(&x.info.clear_depth, &y.info.clear_depth, sizeof(float)) != 0) return false;
@@ -1585,23 +1590,65 @@ static mirhi_result settle_readers(mirhi_device* dev, const uint8_t* lo, const u
     return MIRHI_OK;
 }
 
+#ifdef MIRHI_HOST_PROF
+#include <x86intrin.h>
+static unsigned long long g_hp[8]; static unsigned long long g_hp_n;
+#define HP(k) do { const unsigned long long t_ = __rdtsc(); g_hp[k] += t_ - hp_t; hp_t = t_; } while (0)
+#define HP_BEGIN unsigned long long hp_t = __rdtsc(); g_hp_n++
+extern "C" void mirhi_debug_host_prof(void) { for (int k = 0; k < 8; k++) fprintf(stderr, "host prof [%d] %.1f cycles per call (%llu calls)\n", k, g_hp_n ? (double)g_hp[k] / (double)g_hp_n : 0.0, g_hp_n); }
+#else
+#define HP(k) do {} while (0)
+#define HP_BEGIN do {} while (0)
+#endif
 extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
+    HP_BEGIN;
     REQUIRE_RECORDING(cmd);
     if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
     mirhi_device* dev = cmd->dev;
     if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
         same_recording(cmd->passes, cmd->planned)) {
+        HP(0);
         // The frame recorded last time, recorded again: plan, workspace and parameter block are what they have to be.  No HIP call,
         // no synchronisation, nothing uploaded; only the status words of the previous submission are handed over and re-armed.
         mirhi_result r = settle_pending(cmd);
+        if (r != MIRHI_OK) return r;
+        HP(1);
+        if (cmd->ws.status_host && (cmd->ws.status_host[0] | cmd->ws.status_host[1] | cmd->ws.status_host[2] | cmd->ws.status_host[3])) {
+            HP(2);
+            hand_over_status(cmd);
+            HP(3);
+            cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0; cmd->ws.status_host[3] = 0;
+            HP(4);
+        }
+        cmd->state = CMD_EXECUTABLE;
+        return MIRHI_OK;
+    }
+    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
+        cmd->plan.size() == cmd->passes.size() && cmd->ws.pimage.size() >= cmd->passes.size() * 2 * sizeof(PassParams) && same_recording(cmd->passes, cmd->planned, true)) {
+        // The same frame into another swapchain image: the plan stands, PassParams::color of every scope is rewritten (host copy, both parities in the parameter block).
+        mirhi_result r = settle_pending(cmd);                  // (the block is read by a submission that is still pending: wait for it -- a fenced loop has)
         if (r != MIRHI_OK) return r;
         if (cmd->ws.status_host && (cmd->ws.status_host[0] | cmd->ws.status_host[1] | cmd->ws.status_host[2] | cmd->ws.status_host[3])) {
             hand_over_status(cmd);
             cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0; cmd->ws.status_host[3] = 0;
         }
-        cmd->state = CMD_EXECUTABLE;
-        return MIRHI_OK;
+        if (cmd->ws.replan || cmd->ws.grow_pool || cmd->ws.dirty) goto rebuild;      // (the status just handed over asked for another plan)
+        {
+            HIP_TRY(hipSetDevice(dev->ordinal));
+            hipStream_t stream = dev->lanes[cmd->lane < dev->lanes.size() ? cmd->lane : 0];
+            for (size_t pi = 0; pi < cmd->passes.size(); pi++) {
+                uint8_t* target = const_cast<uint8_t*>(cmd->passes[pi].color_t.ptr);
+                cmd->plan[pi].color = target;
+                for (size_t parity = 0; parity < 2; parity++) reinterpret_cast<PassParams*>(cmd->ws.pimage.data() + (2 * pi + parity) * sizeof(PassParams))->color = target;
+            }
+            if ((r = pblock_commit(cmd->ws, stream)) != MIRHI_OK) { cmd->plan_valid = false; return r; }
+            if (!cmd->ws.pblock_direct) { cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true; }     // (the copy is in the lane's stream)
+            { std::lock_guard<std::mutex> lk(dev->mu); cmd->planned = cmd->passes; }
+            cmd->state = CMD_EXECUTABLE;
+            return MIRHI_OK;
+        }
     }
+rebuild:
     mirhi_result r = build_plan(cmd);
     if (r != MIRHI_OK) { cmd->plan_valid = false; return r; }
     cmd->state = CMD_EXECUTABLE;
@@ -1639,7 +1686,13 @@ static mirhi_result pblock_commit(Workspace& w, hipStream_t stream) {
     if (w.pshadow.size() == n && (n == 0 || memcmp(w.pshadow.data(), w.pimage.data(), n) == 0)) return MIRHI_OK;
     if (n) {
         if (w.pblock_direct) {
-            memcpy(w.pblock, w.pimage.data(), n);          // write-combined stores over the BAR ...
+            // write-combined stores over the BAR, only the 64-byte pieces that differ from what the block holds (a frame loop changes a target address or a count) ...
+            if (w.pshadow.size() == n) {
+                for (size_t o = 0; o < n; o += 64) {
+                    const size_t len = n - o < 64 ? n - o : 64;
+                    if (memcmp(w.pshadow.data() + o, w.pimage.data() + o, len) != 0) memcpy(w.pblock + o, w.pimage.data() + o, len);
+                }
+            } else memcpy(w.pblock, w.pimage.data(), n);
             __builtin_ia32_sfence();                         // ... out of the write-combining buffers before any launch rings a doorbell
         } else {
             memcpy(w.pstage, w.pimage.data(), n);
