@@ -1,3 +1,4 @@
+# Deep-queue rate by number of queue lanes (= frames in flight) and raster variant, C3 and C2: more than four lanes are slower (the command processor has four pipes).
 mkdir -p gpurun_out/r3b
 for w in c3 c2; do
 for f in 2 3 4 6 8; do

@@ -1,3 +1,4 @@
+# Tile-to-XCD run length of a 1-D raster grid (MIRHI_XCD_RUN) on C5 / C4 / C3: rate and isolated raster time.
 mkdir -p gpurun_out/r3b
 for w in c5 c4 c3; do
 for g in 1 2 4 5 15; do
