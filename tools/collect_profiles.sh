@@ -22,7 +22,7 @@ for w in c2 c3 c4 c5; do
   rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $out/pmc_rdreq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_rdreq_$w.err
   echo "collected $w"
 done
-rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
+rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_traced.json 2> $out/trace.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --timeline-out $out/timeline_in_flight.json > $out/bench_default.json 2> $out/bench_default.err
 for w in c3 c4 c5; do python3 bench.py --workload $w --cpu-seconds 8 > $out/bench_$w.json 2>/dev/null; echo "bench $w done"; done
 # summaries are made HERE (the raw traces are too big to travel back), the bulky raw files dropped

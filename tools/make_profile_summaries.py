@@ -119,7 +119,7 @@ busy += cur_e - cur_b
 wall = mid[-1][2] - mid[0][1]
 queues = sorted(set(x[3] for x in rows))
 summary = {
-    "command": "rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline (C2, 4 queue lanes, 512 frames per step)",
+    "command": "rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras (C2, 4 queue lanes, 512 frames per step)",
     "raster_dispatches": len(ras), "geometry_dispatches": len(geo), "hardware_queues_seen": queues,
     "window": f"raster dispatches {lo}..{hi} of {len(ras)} (steady state)",
     "raster_us": round(dur_r, 3), "geometry_us": round(dur_g, 3),
