@@ -1947,6 +1947,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
             bool tri_prog = false;
             for (const DrawDesc& dd : draws) tri_prog |= dd.program == MIRHI_PROGRAM_TRIANGLE;
             P.flat_color = (tri_prog && ci.format == MIRHI_FORMAT_B8G8R8A8_SRGB) ? w.flat_color : nullptr;
+            P.resolve_flat_only = (P.flat_color && !P.depth_load && P.color_format != 2u && !P.prim_out && !(P.depth && P.depth_store)) ? 1u : 0u;
         }
         {
             const RasterMode mode = raster_mode(pass, (size_t)g.tiles_x * (g.r1 - g.r0), w.spread, w.wide);
@@ -2025,6 +2026,7 @@ static mirhi_result stats_params_for(mirhi_cmd* c) {
             P.active = w.counters + CTR_ACTIVE + parity * 8u * 32u;
             P.active_prev = w.counters + CTR_ACTIVE + (parity ^ 1u) * 8u * 32u;
             P.prim_out = w.stats_prim;
+            P.resolve_flat_only = 0u;
             copies.push_back(P);
         }
     if (!copies.empty()) {

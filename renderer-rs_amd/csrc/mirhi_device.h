@@ -164,6 +164,9 @@ struct PassParams {
     // needs neither an allocation nor a table entry.
     uint32_t sub_cap, count_stride;
     uint32_t raster_wide;             // 1: the wide mesh variant, sixteen waves per tile (host-side choice from the busy-tile count, see raster_body)
+    uint32_t resolve_flat_only;       // 1: a wave whose covered pixels all carry a packed flat colour may store and leave (flat colours exist, depth was not loaded,
+                                      // the target is 8-bit, no primitive-id image, no depth store) -- the four conditions as one host-computed word: one scalar load
+                                      // in the resolve instead of four dependent ones
     // Busy-tile count (feedback for that choice): every raster workgroup whose tile holds something adds 1 to active[(tile & 7) * 32] (eight
     // counters, one per XCD residue, a cache line apart); the workgroup of tile 0 reports the sum of the PREVIOUS scope's counters
     // (active_prev: the other parity, complete by then) in status[3] and re-arms them.

@@ -857,7 +857,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // Fast exit for the headline shape of work: every covered pixel of this wave belongs to a flat-coloured
     // triangle whose packed colour the geometry kernel already produced, and only the 8-bit colour target is
     // written.  Same values as the general loop below, a fraction of its instructions.
-    if (flat_color && R->color_format != 2 && !R->prim_out && !(R->depth && R->depth_store)) {
+    if (PROGS == 1 && R->resolve_flat_only) {            // (= flat_color && 8-bit target && no primitive-id image && no depth store, computed by the host)
         // a covered pixel without a flat colour has to be shaded: then the whole wave takes the general loop
         const bool need_shade = (st.idk[0] != init_idk && flat4[0] == 0u) || (st.idk[1] != init_idk && flat4[1] == 0u) ||
                                 (st.idk[2] != init_idk && flat4[2] == 0u) || (st.idk[3] != init_idk && flat4[3] == 0u);
