@@ -113,6 +113,7 @@ namespace {
 struct ImplicitArgs { uint32_t block_count[3]; uint16_t group_size[3]; uint16_t remainder[3]; uint8_t reserved[16]; uint64_t global_offset[3]; uint16_t grid_dims; uint8_t pad[6]; };
 static_assert(sizeof(ImplicitArgs) == 72, "implicit argument block (the part this library fills)");
 constexpr size_t NATIVE_RING_BYTES = 256 * 1024;
+constexpr size_t NATIVE_KERNARG_SLOT = 1024;      // bytes of kernel arguments (explicit + implicit) a packet may have
 constexpr uint32_t NATIVE_QUEUE_PACKETS = 1024;
 
 hsa_status_t native_pick_agent(hsa_agent_t a, void* data) {
@@ -240,12 +241,15 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     std::lock_guard<std::mutex> qlock(nq->mu);
     const size_t explicit_bytes = (args_bytes + 7) & ~(size_t)7;
     const size_t need = (std::max<size_t>(explicit_bytes + sizeof(ImplicitArgs), k->kernarg_bytes) + 63) & ~(size_t)63;
-    if (need > 4096 || explicit_bytes + sizeof(ImplicitArgs) > 4096) return hipErrorInvalidValue;
-    if (nq->ring_pos + need > nq->ring_bytes) nq->ring_pos = 0;
-    // (a ring slot comes round again after >= 256 KB / 4 KB = 64 ... typically > 1000 dispatches; the queue holds 1024 packets in order)
-    while (nq->widx - hsa_queue_load_read_index_relaxed(nq->q) >= NATIVE_QUEUE_PACKETS - 2) cpu_relax();
-    uint8_t* ka = nq->ring + nq->ring_pos;
-    nq->ring_pos += need;
+    if (need > NATIVE_KERNARG_SLOT || explicit_bytes + sizeof(ImplicitArgs) > NATIVE_KERNARG_SLOT) return hipErrorInvalidValue;
+    // Kernel arguments: packet w uses slot w % SLOTS of the ring.  Every packet of this queue carries the barrier bit, so once the packet processor has
+    // CONSUMED packet j + 1 (read index >= j + 2), packet j has finished and its slot is free: at most SLOTS - 2 packets may be outstanding when slot
+    // w % SLOTS is written again.  (Round 3's first version advanced a byte cursor and relied on "more than 1,000 dispatches per lap": with 320-byte
+    // argument blocks a lap was 819 dispatches while the queue admitted 1,022 -- harmless only because a deep queue resubmits identical arguments.)
+    constexpr uint64_t SLOTS = NATIVE_RING_BYTES / NATIVE_KERNARG_SLOT;
+    static_assert(SLOTS >= 64 && SLOTS <= NATIVE_QUEUE_PACKETS, "kernarg ring");
+    while (nq->widx - hsa_queue_load_read_index_scacquire(nq->q) > SLOTS - 2) cpu_relax();
+    uint8_t* ka = nq->ring + (nq->widx % SLOTS) * NATIVE_KERNARG_SLOT;
     alignas(16) uint8_t tmp[4096];
     memcpy(tmp, args, args_bytes);
     if (explicit_bytes > args_bytes) memset(tmp + args_bytes, 0, explicit_bytes - args_bytes);
@@ -335,6 +339,7 @@ struct mirhi_device {
     std::atomic<uint64_t> sq_pushed{0}, sq_done{0};
     std::atomic<bool> sq_stop{false}, sq_sleeping{false};
     std::mutex sq_mu; std::condition_variable sq_cv;
+    std::mutex sq_push_mu;                                    // producers: several host threads may submit to one device (the ring has ONE consumer)
 };
 
 struct mirhi_buffer {
@@ -2152,6 +2157,7 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         return submit_now(dev, cmd_count, cmds, fence);
     }
     // Submit thread on: the job is queued, the launches happen there.  What the caller may look at next is set here, in its own thread.
+    std::lock_guard<std::mutex> producer(dev->sq_push_mu);
     const uint64_t slot = dev->sq_pushed.load(std::memory_order_relaxed);
     while (slot - dev->sq_done.load(std::memory_order_acquire) >= mirhi_device::SQ_SLOTS) cpu_relax();
     mirhi_device::SubmitJob& job = dev->sq_ring[slot % mirhi_device::SQ_SLOTS];

@@ -340,3 +340,22 @@ def test_buffers_rewritten_between_frames_are_seen_by_the_next_frame(mirhi, orac
         res.render(fence); fence.wait(); fence.reset()
         _check(_read(res), oracle.render(sc, want_bgra8=False), f"{upload}: frame {k}")
     res.destroy(); fence.destroy(); dev.destroy()
+
+
+def test_a_deep_queue_of_different_command_buffers_on_one_lane(mirhi, oracle, scenes):
+    """A thousand submissions on ONE queue lane without a single wait, alternating between command buffers of different shape (other kernels'
+    arguments every packet): the kernel-argument ring of the lane's AQL queue must not hand a slot out again before the packet that reads it has
+    finished (round 3's first version could, once more than 819 packets were outstanding).  Both targets end up as the oracle's frames."""
+    dev = mirhi.Device(0)
+    a = scenes.random_triangles(2500, 640, 360, seed=5)
+    b = scenes.displaced_sphere(24, 17, 320, 200, seed=9)
+    ra = mirhi.SceneResources(dev, a, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    rb = mirhi.SceneResources(dev, b, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    ra.cmd.set_queue_lane(0); rb.cmd.set_queue_lane(0)
+    ra.record(); rb.record()
+    for k in range(1500):
+        (ra if k % 2 == 0 else rb).render()
+    dev.wait_idle()
+    _check(_read(ra), oracle.render(a, want_bgra8=False), "scene A behind 1,500 queued submissions")
+    _check(_read(rb), oracle.render(b, want_bgra8=False), "scene B behind 1,500 queued submissions")
+    ra.destroy(); rb.destroy(); dev.destroy()
