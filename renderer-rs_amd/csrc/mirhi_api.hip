@@ -195,6 +195,26 @@ void native_queue_close(mirhi::NativeQueue* nq) {
 }
 
 // every packet written to the queue so far has completed (a barrier packet with a completion signal, waited for on the host)
+// Waits until a completion signal reads 0 (or `timeout_ns` has passed: false).  A frame's fence is due within microseconds: poll the word in host
+// memory for 200 us, then block in the runtime (interrupt-driven, in slices of at most 10 ms so that a timeout is honoured) -- a thread that waits
+// for seconds of GPU work must not keep a core spinning.
+bool native_signal_wait(hsa_signal_t sig, uint64_t timeout_ns) {
+    static const uint64_t ticks_per_s = [] { uint64_t f = 0; return hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &f) == HSA_STATUS_SUCCESS && f ? f : 100000000ull; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; it++) {
+        if (hsa_signal_load_scacquire(sig) == 0) return true;
+        cpu_relax();
+        if ((it & 1023u) != 1023u) continue;
+        const uint64_t elapsed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_ns != UINT64_MAX && elapsed >= timeout_ns) return false;
+        if (elapsed >= 200000ull) {
+            uint64_t slice_ns = 10000000ull;
+            if (timeout_ns != UINT64_MAX && timeout_ns - elapsed < slice_ns) slice_ns = timeout_ns - elapsed;
+            (void)hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_EQ, 0, slice_ns * ticks_per_s / 1000000000ull + 1ull, HSA_WAIT_STATE_BLOCKED);
+        }
+    }
+}
+
 void native_queue_drain(mirhi::NativeQueue* nq) {
     if (!nq) return;
     std::lock_guard<std::mutex> qlock(nq->mu);
@@ -210,7 +230,7 @@ void native_queue_drain(mirhi::NativeQueue* nq) {
     nq->widx++;
     hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
     hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)(nq->widx - 1));
-    while (hsa_signal_load_scacquire(nq->drain_sig) != 0) cpu_relax();
+    (void)native_signal_wait(nq->drain_sig, UINT64_MAX);
     nq->drained = nq->widx;
 }
 }  // namespace
@@ -248,7 +268,7 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     // argument blocks a lap was 819 dispatches while the queue admitted 1,022 -- harmless only because a deep queue resubmits identical arguments.)
     constexpr uint64_t SLOTS = NATIVE_RING_BYTES / NATIVE_KERNARG_SLOT;
     static_assert(SLOTS >= 64 && SLOTS <= NATIVE_QUEUE_PACKETS, "kernarg ring");
-    while (nq->widx - hsa_queue_load_read_index_scacquire(nq->q) > SLOTS - 2) cpu_relax();
+    for (uint32_t spins = 1; nq->widx - hsa_queue_load_read_index_scacquire(nq->q) > SLOTS - 2; spins++) { cpu_relax(); if ((spins & 4095u) == 0u) std::this_thread::yield(); }   // (back-pressure of a full queue)
     uint8_t* ka = nq->ring + (nq->widx % SLOTS) * NATIVE_KERNARG_SLOT;
     alignas(16) uint8_t tmp[4096];
     memcpy(tmp, args, args_bytes);
@@ -2468,13 +2488,9 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
     }
     if (f->native_wait) {
         // native dispatch: the completion signal of the submission's last packet, a word in host memory (1 -> 0)
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t it = 0;; it++) {
-            if (hsa_signal_load_scacquire(f->native_sig) == 0) { f->native_wait = false; return fence_complete(f); }
-            cpu_relax();
-            if ((it & 1023u) == 1023u && timeout_ns != UINT64_MAX && (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ns)
-                return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
-        }
+        if (!native_signal_wait(f->native_sig, timeout_ns)) return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        f->native_wait = false;
+        return fence_complete(f);
     }
     HIP_TRY(hipSetDevice(f->dev->ordinal));
     if (timeout_ns == UINT64_MAX) {
@@ -2507,7 +2523,7 @@ extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
     if (f->pending) {   // resetting a fence that is still in flight is invalid in Vulkan; drain it first
         while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
         HIP_TRY(hipSetDevice(f->dev->ordinal));
-        if (f->native_wait) { while (hsa_signal_load_scacquire(f->native_sig) != 0) cpu_relax(); f->native_wait = false; }
+        if (f->native_wait) { (void)native_signal_wait(f->native_sig, UINT64_MAX); f->native_wait = false; }
         else HIP_TRY(hipEventSynchronize(f->event));
         (void)fence_complete(f);
     }
@@ -2533,7 +2549,7 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     (void)hipSetDevice(f->dev->ordinal);
     while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
-    if (f->pending && f->native_wait) { while (hsa_signal_load_scacquire(f->native_sig) != 0) cpu_relax(); }
+    if (f->pending && f->native_wait) (void)native_signal_wait(f->native_sig, UINT64_MAX);
     else if (f->pending && f->event) (void)hipEventSynchronize(f->event);
     if (f->native_sig.handle) (void)hsa_signal_destroy(f->native_sig);
     if (f->event) (void)hipEventDestroy(f->event);

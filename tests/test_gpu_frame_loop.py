@@ -359,3 +359,28 @@ def test_a_deep_queue_of_different_command_buffers_on_one_lane(mirhi, oracle, sc
     _check(_read(ra), oracle.render(a, want_bgra8=False), "scene A behind 1,500 queued submissions")
     _check(_read(rb), oracle.render(b, want_bgra8=False), "scene B behind 1,500 queued submissions")
     ra.destroy(); rb.destroy(); dev.destroy()
+
+
+def test_a_fence_behind_milliseconds_of_work_times_out_and_then_completes(mirhi, oracle, scenes):
+    """A fence whose submission sits behind ~10 ms of queued frames: wait(0.5 ms) reports TIMEOUT (the wait polls, then blocks in the runtime in
+    slices and still honours the timeout), the status is NOT_READY meanwhile, an unbounded wait then returns with the frame complete and right."""
+    import time
+    dev = mirhi.Device(0)
+    scene = scenes.heightfield_grid(256, 256, 1920, 1080)           # 131k triangles: a few tens of microseconds per frame
+    res = mirhi.SceneResources(dev, scene, mirhi.Format.R32G32B32A32_SFLOAT, want_prim=True)
+    fence = mirhi.Fence(dev)
+    res.render(); dev.wait_idle()
+    for _ in range(300):                                             # >= 9 ms of queued work on this command buffer's lane
+        res.render()
+    res.render(fence)
+    t0 = time.perf_counter()
+    with pytest.raises(mirhi.RhiError) as e:
+        fence.wait(timeout_ns=500_000)
+    waited = time.perf_counter() - t0
+    assert e.value.code == mirhi.TIMEOUT
+    assert 0.0004 < waited < 0.05, f"a 0.5 ms timeout returned after {1e3 * waited:.2f} ms"
+    assert not fence.is_signaled()
+    fence.wait()
+    assert fence.is_signaled()
+    _check(_read(res), oracle.render(scene, want_bgra8=False), "frame behind the long queue")
+    res.destroy(); fence.destroy(); dev.destroy()
