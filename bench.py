@@ -60,9 +60,11 @@ def parse_args():
                     help="command buffers handed to one mirhi_queue_submit call (vkQueueSubmit with several command buffers): frames of "
                          "equal shape then share one batch of kernel launches; frames in flight = this x --frames-in-flight")
     ap.add_argument("--record-each-frame", action="store_true",
-                    help="the timed region itself is the reference-shaped loop: every frame waits on its in-flight fence, resets and RE-RECORDS "
-                         "its command buffer, ends and submits it with the fence (renderer.rs:367-449,452-557), natively through libmirhost.so. "
-                         "Without the flag that loop is measured beside the headline (rerecorded_submit)")
+                    help="(the default on one GPU since round 4) the timed region is the reference-shaped loop: every frame waits on its in-flight fence, "
+                         "resets and RE-RECORDS its command buffer, ends and submits it with the fence (renderer.rs:367-449,452-557), natively through "
+                         "libmirhost.so; the resubmitted rate is measured beside it (resubmitted_submit)")
+    ap.add_argument("--resubmit", action="store_true",
+                    help="the timed region resubmits command buffers recorded once (the headline of rounds 1-3) instead of re-recording every frame")
     ap.add_argument("--other-workloads", default="c3,c4,c5", help="N = 1: short passes of these workloads after the headline (workloads{} in the line); '' = none")
     ap.add_argument("--profile-pass-only", action="store_true",
                     help="skip the timed region: only the per-dispatch timing passes (the command profiled with rocprofv3 --pmc)")
@@ -238,7 +240,9 @@ def main():
 
         def __init__(self, lanes, band=None, rows=None, per_submit=1, dev=None, scene=scene):
             self.owns_dev = dev is None
-            self.dev = dev or m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+            # one GPU: a device with a stream of its own (every queue lane dispatches natively); several: on torch's stream, whose order the
+            # torch.distributed fallback of the band exchange relies on (include/mirhi.h, mirhi_device_create_on_stream)
+            self.dev = dev or (m.Device(local_rank) if world == 1 else m.Device(local_rank, stream=torch.cuda.current_stream().cuda_stream))
             self.scene = scene
             if self.owns_dev:
                 self.dev.set_queue_lanes(lanes)
@@ -359,7 +363,8 @@ def main():
                     multigpu.all_gather_bands(rig.frames[rig.slots.index(sl)], rank, world, via_host=(args.backend == "gloo"))
 
     floop = None
-    if args.record_each_frame:
+    record_each = args.record_each_frame or (world == 1 and not split and per_submit == 1 and not args.resubmit and not args.profile_pass_only)
+    if record_each:
         if split or world > 1 or per_submit != 1:
             raise SystemExit("bench.py: --record-each-frame measures the one-GPU frame loop (no split, one frame per submit)")
         from renderer_rs_amd import frameloop
@@ -388,11 +393,38 @@ def main():
             step()
     dev.wait_idle()                           # also reports (and acts on) the device status of the warm-up frames: a bin pool that
     barrier()                                 # turned out too small is grown before the timed region, not inside it
+    stats_before = dev.stats()
     t0 = time.perf_counter()
     for _ in range(0 if args.profile_pass_only else args.steps):
         step()
     barrier()
     dt = max_over_ranks(max(time.perf_counter() - t0, 1e-9))
+    stats_after = dev.stats()
+
+    # ---- the frames the timed region produced, against the oracle (the checker; never inside the timed region) ------------------------
+    # every colour target the loop rendered into (the swapchain images of the re-recorded loop / each lane's target of the resubmitted one) is read
+    # back and compared with the frame the CPU oracle renders of the same scene: <= 1 code per channel of the sRGB8 target, 1e-4 on a float one.
+    verify = None
+    if world == 1 and not args.profile_pass_only and not split:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            ref = ob.render(scene, nthreads=max(1, min(os.cpu_count() or 1, 64)), want_bgra8=(bpp == 4))
+            ref_img = ref["bgra8"] if bpp == 4 else ref["rgba"]
+            targets = getattr(rig, "extra_images", []) if floop is not None else [sl.color for sl in rig.slots[:nfif * per_submit]]
+            worst, checked = 0.0, 0
+            for img in targets:
+                got = img.read()
+                d = np.abs(got.astype(np.int32) - ref_img.astype(np.int32)) if bpp == 4 else np.abs(got[..., :3] - ref_img[..., :3])
+                worst = max(worst, float(d.max()))
+                checked += 1
+            tol = 1.0 if bpp == 4 else 1e-4
+            verify = {"frames_verified": checked if worst <= tol else 0, "targets": checked, "max_abs_diff": worst, "tolerance": tol,
+                      "unit": "sRGB8 codes" if bpp == 4 else "linear float", "against": "oracle/mirhi_oracle.c frame of the same scene"}
+            if worst > tol:
+                print(f"bench.py: the timed region's frames differ from the oracle's by {worst} (> {tol}): the line is not to be trusted", file=sys.stderr, flush=True)
+        except Exception as e:
+            verify = {"frames_verified": 0, "error": repr(e)}
 
     if split and not args.profile_pass_only:
         # every rank must now hold the same, complete frame
@@ -443,7 +475,12 @@ def main():
         shaded, covered, _scopes = dev.fragment_stats()
     dev.reset_kernel_times()
     stats = dev.stats()
+    dispatch_path = dev.dispatch_path()
+    build_id = m.lib().mirhi_build_id().decode()
     extras = {}
+    if verify is not None:
+        extras["frames_verified"] = verify.pop("frames_verified")
+        extras["verification"] = verify
     if world == 1 and per_submit == 1 and not args.no_extras and not args.profile_pass_only:
         # the same frame loop with 8 command buffers per mirhi_queue_submit call (vkQueueSubmit with several command buffers): the
         # frames of a call share one batch of launches.  Same device and queue lanes (a second device would be dealt other hardware
@@ -508,6 +545,11 @@ def main():
         except Exception as e:
             extras["rerecorded_submit"] = {"error": repr(e)}
         try:
+            # the headline of rounds 1-3: the same command buffers recorded once and resubmitted round-robin, no fences (the lanes queue up)
+            extras["resubmitted_submit"] = resubmitted(rig, rig.slots[:nfif], n_re)
+        except Exception as e:
+            extras["resubmitted_submit"] = {"error": repr(e)}
+        try:
             if os.environ.get("MIRHI_BENCH_SKIP_FIF2"):
                 raise RuntimeError("skipped (MIRHI_BENCH_SKIP_FIF2)")
             # the reference's MAX_FRAMES_IN_FLIGHT = 2 (crates/renderer/src/lib.rs:43): two queue lanes, two command buffers
@@ -518,6 +560,23 @@ def main():
                 sl.cmd.set_queue_lane(i)
             n2 = max(512, 2 * fps)
             extras["frames_in_flight_2"] = {"resubmitted": resubmitted(rig, two, n2), "rerecorded": rerecorded(rig, 2, n2, phases=True)}
+            # Where a fence-gated frame's microseconds go: ONE frame in flight is the whole chain per frame (host -> doorbell -> geometry -> raster ->
+            # signal -> host); its parts measured separately: host phases (clock reads in the native loop), the kernels alone (event pairs), the round trip
+            # of an empty one-wave kernel on the same queue (doorbell -> packet processor -> wave -> release -> signal -> host: everything around the
+            # kernels that is not the host's) and of a barrier packet (no wave).  What is left is the boundary between the two kernels plus whatever the
+            # parts cost more when chained than alone.
+            one = rerecorded(rig, 1, max(256, n2 // 2), phases=True)
+            rt_kernel, rt_barrier = dev.measure_roundtrip(0, 300)
+            g_us = 1e3 * iso["geometry"][0] / max(1, iso["geometry"][1]); r_us = 1e3 * iso["raster"][0] / max(1, iso["raster"][1]); v_us = 1e3 * iso["vertex"][0] / max(1, iso["vertex"][1])
+            hostp = one["host_us_per_frame"]
+            host_us = hostp["record"] + hostp["end"] + hostp["submit"]
+            extras["frames_in_flight_2"]["chain_us"] = {
+                "frame_latency_one_in_flight": one["us_per_frame"], "host": round(host_us, 3), "host_phases": {k: hostp[k] for k in ("record", "end", "submit")},
+                "doorbell_to_wave_plus_signal_to_host": round(rt_kernel, 3), "barrier_packet_round_trip": round(rt_barrier, 3),
+                "vertex": round(v_us, 3), "geometry": round(g_us, 3), "raster": round(r_us, 3),
+                "boundary_and_rest": round(one["us_per_frame"] - host_us - rt_kernel - g_us - r_us - v_us, 3),
+                "how": "frame_latency = us per frame of the re-recorded loop with ONE frame in flight; host = its record + end + submit phases; doorbell..host = round trip "
+                       "of an empty one-wave kernel on the same AQL queue (mirhi_device_measure_roundtrip); kernels = isolated durations (event pairs); the rest by difference"}
             dev.wait_idle()
             dev.set_queue_lanes(nfif)
             for i, sl in enumerate(rig.slots[:nfif]):
@@ -626,8 +685,13 @@ def main():
                                        else (f"afr{world}" if world > 1 else "single")),
                        "frames_per_step": fps, "prewarm_seconds": args.prewarm_seconds, "frames_in_flight": nfif * per_submit, "queue_lanes": nfif, "frames_per_submit": per_submit,
                        "command_buffers": "re-recorded every frame (wait fence, reset, record, end, submit with fence: renderer.rs:367-557), native loop"
-                                          if args.record_each_frame else "recorded once, resubmitted"},
+                                          if record_each else "recorded once, resubmitted"},
             "timed_region_s": round(dt, 6), "us_per_frame": round(1e6 * dt / max(1, args.steps * fps), 4),
+            # how the timed region's kernels left the library (include/mirhi.h, mirhi_device_dispatch_path): hand-written AQL packets or HIP launches --
+            # a silent fallback would show here -- and how many of each the timed region made
+            "dispatch_path": dispatch_path, "native_dispatches": int(stats_after.native_dispatches - stats_before.native_dispatches) & 0xFFFFFFFF,
+            "frames_submitted": int(stats_after.frames_submitted - stats_before.frames_submitted),
+            "build_id": build_id, "build_matches_sources": build_id == src_hash,
             "shaded_mpix_per_s": round(shaded_per_frame * frames_total / dt / 1e6, 1),
             "overdraw": round(covered / shaded, 4) if shaded else None,
             "shaded_pixels_per_frame": int(shaded_per_frame), "covered_fragments_per_frame": int(covered / max(1, stat_frames)),

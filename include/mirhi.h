@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define MIRHI_ABI_VERSION 4u     /* 3: mirhi_pipeline_desc.fragment_discard_enable; 4: mirhi_device_set_submit_thread */
+#define MIRHI_ABI_VERSION 5u     /* 3: mirhi_pipeline_desc.fragment_discard_enable; 4: mirhi_device_set_submit_thread; 5: mirhi_device_set_native_dispatch,
+                                    mirhi_device_dispatch_path, mirhi_device_measure_roundtrip, mirhi_build_id, mirhi_device_stats grew four words */
 
 /* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
 typedef int32_t mirhi_result;
@@ -62,6 +63,12 @@ mirhi_result mirhi_device_count(int32_t* out_count);                      /* phy
 mirhi_result mirhi_device_create(int32_t hip_ordinal, mirhi_device** out);
 /* same, but all work is issued on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
 mirhi_result mirhi_device_create_on_stream(int32_t hip_ordinal, void* hip_stream, mirhi_device** out);
+/* Native dispatch (csrc/mirhi_native.h): a plain submit leaves the library as AQL packets on a ROCr queue of the lane's own, NOT on a HIP stream.  A device
+ * made by mirhi_device_create does that on every lane.  A device made on the caller's stream keeps the promise above for queue lane 0 -- submits to lane 0
+ * are HIP launches on `hip_stream`, ordered against whatever else the caller put there -- and dispatches natively only on the lanes the library created
+ * (mirhi_device_set_queue_lanes), which were never ordered against that stream.  enable = 1 opts lane 0 in as well: the caller then orders its own stream
+ * against the frames with fences / wait_idle (hipStreamSynchronize knows nothing about the device's queues).  enable = 0: back to the default. */
+mirhi_result mirhi_device_set_native_dispatch(mirhi_device* dev, uint32_t enable);
 mirhi_result mirhi_device_wait_idle(mirhi_device* dev);                   /* Device::wait_idle :290-293; also reports (once) the device-side
                                                                              status of frames submitted without a fence, as mirhi_fence_wait does */
 mirhi_result mirhi_device_destroy(mirhi_device* dev);                     /* fails if children are alive */
@@ -315,8 +322,21 @@ typedef struct {
     uint32_t last_bin_pages;        /* 2 KB bin pages the last finished scope took from the pool (beyond each tile's fixed first page) */
     uint32_t native_dispatches;     /* kernels this device dispatched as AQL packets on its own ROCr queues (csrc/mirhi_native.h) instead of through
                                        HIP launches (low 32 bits of the count); 0 on a device whose native dispatcher could not start */
+    uint32_t dispatch_path;         /* how a plain submit leaves the library: 0 HIP launches (mirhi_device_dispatch_path says why), 1 AQL packets on the
+                                       device's own hardware queues, 2 AQL packets on a queue a tool intercepts (MIRHI_NATIVE_DISPATCH=2 only) */
+    uint32_t device_lost;           /* 1: a wait on one of the device's queues ran into its deadline; every later submit and wait fails with VulkanError */
+    uint32_t reserved;
 } mirhi_device_stats;
 mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_stats* out);
+/* "native: ..." or "hip: <why the native dispatcher is not used>", NUL-terminated into out[0 .. out_len) */
+mirhi_result mirhi_device_dispatch_path(mirhi_device* dev, char* out, uint32_t out_len);
+/* Measurement: round trip of ONE dispatch on queue lane `lane`, host store of the packet -> host sees its completion signal, averaged over `reps` dispatches
+ * one at a time: [0] an empty one-wave kernel (doorbell -> packet processor -> wave -> end-of-kernel release -> signal -> host), [1] a barrier packet (no
+ * wave).  What a fence-gated frame pays around its kernels.  Fails with LoadingError on a device without native dispatch. */
+mirhi_result mirhi_device_measure_roundtrip(mirhi_device* dev, uint32_t lane, uint32_t reps, double* out_us /* [2] */);
+/* the build this library is: first 16 hex digits of the sha256 over csrc/ and include/mirhi.h (renderer-rs_amd/build.py::source_hash).  The code object the
+ * native dispatcher loads (libmirhi_kernels.hsaco) carries the same id and is refused if it differs. */
+const char* mirhi_build_id(void);
 
 /* ---- multi-GPU: screen-tile-row split + exchange of the finished RGBA bands over RCCL / xGMI ------------------
  * The reference drives one VkDevice (crates/rhi/src/device.rs:61-77) and has nothing to mirror here; BASELINE.json's north_star

@@ -102,7 +102,7 @@ class GatherAlgo:
     DIRECT, BROADCAST = range(2)
 
 
-ABI_VERSION = 4                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
+ABI_VERSION = 5                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
 COMM_ID_BYTES = 128
 
 
@@ -151,7 +151,8 @@ class DispatchTime(C.Structure):
 
 class DeviceStats(C.Structure):
     _fields_ = [("frames_submitted", C.c_uint64), ("triangles_submitted", C.c_uint64), ("workspace_bytes", C.c_uint64),
-                ("last_big_list", C.c_uint32), ("last_status", C.c_uint32), ("last_bin_pages", C.c_uint32), ("native_dispatches", C.c_uint32)]
+                ("last_big_list", C.c_uint32), ("last_status", C.c_uint32), ("last_bin_pages", C.c_uint32), ("native_dispatches", C.c_uint32),
+                ("dispatch_path", C.c_uint32), ("device_lost", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class RhiError(RuntimeError):
@@ -247,6 +248,10 @@ _SIGNATURES = {
     "mirhi_comm_all_gather_bands": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mirhi_comm_destroy": (C.c_int32, [C.c_void_p]),
     "mirhi_device_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(DeviceStats)]),
+    "mirhi_device_dispatch_path": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint32]),
+    "mirhi_device_measure_roundtrip": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+    "mirhi_device_set_native_dispatch": (C.c_int32, [C.c_void_p, C.c_uint32]),
+    "mirhi_build_id": (C.c_char_p, []),
 }
 
 
@@ -352,6 +357,21 @@ class Device:
         s = DeviceStats()
         check(lib().mirhi_device_get_stats(self.handle, C.byref(s)))
         return s
+
+    def dispatch_path(self) -> str:
+        """'native: ...' or 'hip: <why>' (mirhi_device_dispatch_path)."""
+        buf = C.create_string_buffer(512)
+        check(lib().mirhi_device_dispatch_path(self.handle, buf, 512))
+        return buf.value.decode()
+
+    def measure_roundtrip(self, lane: int = 0, reps: int = 200):
+        """(empty-kernel round trip, barrier-packet round trip) in microseconds on queue lane `lane` (mirhi_device_measure_roundtrip)."""
+        out = (C.c_double * 2)()
+        check(lib().mirhi_device_measure_roundtrip(self.handle, lane, reps, out))
+        return out[0], out[1]
+
+    def set_native_dispatch(self, enable: bool):
+        check(lib().mirhi_device_set_native_dispatch(self.handle, 1 if enable else 0))
 
     def submit(self, cmds: Sequence["CommandBuffer"], fence: Optional["Fence"] = None):
         """vkQueueSubmit (crates/renderer/src/renderer.rs:407-424)."""

@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     objs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, s + suffix + ".o")
-        cmd = [hipcc(), *FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc(), *FLAGS, *extra_flags, f'-DMIRHI_SOURCE_HASH="{source_hash()}"', "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
+#include <hsa/amd_hsa_signal.h>
 #include <rccl/rccl.h>     // types and prototypes only: librccl is loaded with dlopen on first use (no link-time dependency)
 
 #include "../../include/mirhi.h"
@@ -86,6 +87,11 @@ static inline void cpu_relax() { __builtin_ia32_pause(); }
 // ------------------------------------------------------------------------------------------------
 // native dispatch: AQL packets written by this library (mirhi_native.h)
 // ------------------------------------------------------------------------------------------------
+#ifndef MIRHI_SOURCE_HASH
+#define MIRHI_SOURCE_HASH "unknown"           // build.py passes the hash of csrc/ + include/mirhi.h to BOTH translation units
+#endif
+extern "C" const char* mirhi_build_id(void) { return MIRHI_SOURCE_HASH; }
+
 namespace mirhi {
 struct NativeKernel { uint64_t object; uint32_t kernarg_bytes, lds_bytes, scratch_bytes; };
 struct NativeDevice {
@@ -96,15 +102,19 @@ struct NativeDevice {
     bool ok = false;
     std::string why;
     std::atomic<uint64_t> dispatches{0};
+    std::atomic<bool> lost{false};           // a wait on one of this device's queues ran into its deadline: nothing more is dispatched, every wait fails
+    std::string lost_why;
+    uint64_t timeout_ns = 10000000000ull;    // deadline of every native wait WITHOUT progress (MIRHI_NATIVE_TIMEOUT_MS)
 };
 struct NativeQueue {
     NativeDevice* nd = nullptr;
     hsa_queue_t* q = nullptr;
     uint8_t* ring = nullptr;                 // kernel arguments: fine-grained device memory, host-written
-    size_t ring_bytes = 0, ring_pos = 0;
+    size_t ring_bytes = 0;
     uint64_t widx = 0, drained = 0;          // packets written so far / packets known to have completed
     hsa_signal_t drain_sig{};
     uint64_t seen_foreign = 0;               // mirhi_device::foreign_writes at this queue's last system-scope acquire
+    bool proxy = false;                      // hsa_queue_create handed out a software queue (a tool intercepts the packets): see native_queue_open
     std::mutex mu;                           // one producer at a time (a host thread that waits for the queue also writes a packet)
 };
 }  // namespace mirhi
@@ -116,13 +126,33 @@ constexpr size_t NATIVE_RING_BYTES = 256 * 1024;
 constexpr size_t NATIVE_KERNARG_SLOT = 1024;      // bytes of kernel arguments (explicit + implicit) a packet may have
 constexpr uint32_t NATIVE_QUEUE_PACKETS = 1024;
 
+// environment switches read ONCE (getenv walks the whole environment: ~0.1 us each, and a submit asked five of them)
+struct NativeEnv {
+    int dispatch = 1;            // MIRHI_NATIVE_DISPATCH: 0 off, 1 on where available, 2 required (a device that cannot start it fails to create)
+    int system_scope = 0;        // MIRHI_NATIVE_SYSTEM_SCOPE: 1 system scope on every packet, 2 on every scope's first (A/B runs)
+    int geom_tpw = 0;            // MIRHI_GEOM_TPW: triangles per geometry wave of small scopes (16 / 32 / 64; 0 = the host's choice)
+    bool no_batch = false, fence_record = false;
+    uint64_t timeout_ns = 10000000000ull;
+    NativeEnv() {
+        auto num = [](const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; };
+        dispatch = num("MIRHI_NATIVE_DISPATCH", 1); system_scope = num("MIRHI_NATIVE_SYSTEM_SCOPE", 0);
+        geom_tpw = num("MIRHI_GEOM_TPW", 0);
+        no_batch = getenv("MIRHI_NO_BATCH") != nullptr; fence_record = getenv("MIRHI_FENCE_RECORD") != nullptr;
+        const int ms = num("MIRHI_NATIVE_TIMEOUT_MS", 10000);
+        timeout_ns = (uint64_t)(ms > 0 ? ms : 10000) * 1000000ull;
+    }
+};
+const NativeEnv& native_env() { static const NativeEnv e; return e; }
+
+struct PickAgent { uint32_t domain, bdf; hsa_agent_t found{}; uint32_t matches = 0; };
 hsa_status_t native_pick_agent(hsa_agent_t a, void* data) {
-    auto* want = static_cast<std::pair<uint32_t, hsa_agent_t*>*>(data);      // PCI bus:device.function of the HIP device
+    auto* want = static_cast<PickAgent*>(data);      // PCI domain and bus:device.function of the HIP device
     hsa_device_type_t t;
     if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS || t != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
-    uint32_t bdf = 0;
+    uint32_t bdf = 0, domain = 0;
     if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
-    if ((bdf & 0xFFFFu) == (want->first & 0xFFFFu) && want->second->handle == 0) *want->second = a;
+    if (hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain) != HSA_STATUS_SUCCESS) domain = 0;
+    if ((bdf & 0xFFFFu) == (want->bdf & 0xFFFFu) && domain == want->domain) { if (want->matches++ == 0) want->found = a; }
     return HSA_STATUS_SUCCESS;
 }
 
@@ -141,17 +171,18 @@ std::string native_code_object_path() {
 mirhi::NativeDevice* native_device_open(int ordinal) {
     auto* nd = new mirhi::NativeDevice();
     auto fail_with = [&](const std::string& w) { nd->why = w; return nd; };
-    if (getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 0) return fail_with("switched off (MIRHI_NATIVE_DISPATCH=0)");
-    // rocprofv3 --pmc rewrites the packets of the queues it intercepts; a process under counter collection hung at its first hand-written packet
-    // (round 3, tools/collect_profiles.sh) -- under it every launch goes through HIP (the kernels and their counters are the same).  --kernel-trace alone is fine.
-    if (getenv("ROCPROF_COUNTER_COLLECTION") && !(getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 2))
-        return fail_with("rocprofv3 counter collection is on in this process");
+    nd->timeout_ns = native_env().timeout_ns;
+    if (native_env().dispatch == 0) return fail_with("switched off (MIRHI_NATIVE_DISPATCH=0)");
     if (hsa_init() != HSA_STATUS_SUCCESS) return fail_with("hsa_init failed");
-    int bus = 0, devid = 0;
+    int bus = 0, devid = 0, domain = 0;
     if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, ordinal) != hipSuccess || hipDeviceGetAttribute(&devid, hipDeviceAttributePciDeviceId, ordinal) != hipSuccess) { (void)hipGetLastError(); return fail_with("no PCI id for the HIP device"); }
-    std::pair<uint32_t, hsa_agent_t*> want{(uint32_t)((bus << 8) | (devid << 3)), &nd->agent};
+    if (hipDeviceGetAttribute(&domain, hipDeviceAttributePciDomainID, ordinal) != hipSuccess) { (void)hipGetLastError(); domain = 0; }
+    // the ROCr agent of the HIP ordinal: PCI domain AND bus:device.function (hosts with several PCI domains repeat bus numbers); an ambiguous match is refused
+    PickAgent want; want.domain = (uint32_t)domain; want.bdf = (uint32_t)((bus << 8) | (devid << 3));
     (void)hsa_iterate_agents(native_pick_agent, &want);
-    if (nd->agent.handle == 0) return fail_with("no ROCr agent with the HIP device's PCI id");
+    if (want.matches == 0) return fail_with("no ROCr agent with the HIP device's PCI address");
+    if (want.matches > 1) return fail_with("several ROCr agents share the HIP device's PCI address");
+    nd->agent = want.found;
     const std::string path = native_code_object_path();
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return fail_with(path + " is missing (build.py writes it)");
@@ -163,6 +194,17 @@ mirhi::NativeDevice* native_device_open(int ordinal) {
     if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &nd->exe) != HSA_STATUS_SUCCESS) return fail_with("executable create");
     if (hsa_executable_load_agent_code_object(nd->exe, nd->agent, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return fail_with("code object load (is " + path + " of this build?)");
     if (hsa_executable_freeze(nd->exe, nullptr) != HSA_STATUS_SUCCESS) return fail_with("executable freeze");
+    // The code object must be the one this library was built with: a stale pair with another kernel-argument layout would dispatch garbage.  Both
+    // translation units carry the build's source hash (build.py: -DMIRHI_SOURCE_HASH); the code object's copy is the device variable mirhi::g_build_id.
+    {
+        hsa_executable_symbol_t sym; uint64_t addr = 0; char theirs[32] = {0};
+        if (hsa_executable_get_symbol_by_name(nd->exe, "_ZN5mirhi10g_build_idE", &nd->agent, &sym) != HSA_STATUS_SUCCESS ||
+            hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_VARIABLE_ADDRESS, &addr) != HSA_STATUS_SUCCESS || !addr ||
+            hsa_memory_copy(theirs, reinterpret_cast<void*>(addr), 17) != HSA_STATUS_SUCCESS)
+            return fail_with(path + " carries no build id (built by another build.py?)");
+        theirs[17] = 0;
+        if (strcmp(theirs, MIRHI_SOURCE_HASH) != 0) return fail_with(path + " is of build " + theirs + ", this library of build " MIRHI_SOURCE_HASH);
+    }
     nd->ok = true;
     return nd;
 }
@@ -176,10 +218,22 @@ bool native_upload_symbol(mirhi::NativeDevice* nd, const char* name, const void*
     return hsa_memory_copy(reinterpret_cast<void*>(addr), src, bytes) == HSA_STATUS_SUCCESS;
 }
 
+// Is this queue the hardware's, or a software queue a tool put in front of it?  Under rocprofv3 counter collection (and any tool that registers with ROCr's
+// queue-intercept API) hsa_queue_create returns a PROXY: its packets are consumed by a handler that runs inside the doorbell signal's store, rewritten
+// (completion signals swapped, PM4 packets put around each dispatch) and copied to the real queue.  On a proxy `read_index` means "copied", not
+// "consumed by the packet processor", so nothing about completion may be concluded from it.  The public signal ABI (hsa/amd_hsa_signal.h) tells the two apart:
+// a hardware queue's doorbell signal is of kind AMD_SIGNAL_KIND_DOORBELL (a mapped doorbell register), a proxy's is an ordinary user signal.
+bool native_queue_is_proxy(const hsa_queue_t* q) {
+    const amd_signal_t* s = reinterpret_cast<const amd_signal_t*>(q->doorbell_signal.handle);
+    return !s || (s->kind != AMD_SIGNAL_KIND_DOORBELL && s->kind != AMD_SIGNAL_KIND_LEGACY_DOORBELL);
+}
+
 mirhi::NativeQueue* native_queue_open(mirhi::NativeDevice* nd) {
     auto* nq = new mirhi::NativeQueue();
     nq->nd = nd;
     if (hsa_queue_create(nd->agent, NATIVE_QUEUE_PACKETS, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &nq->q) != HSA_STATUS_SUCCESS) { delete nq; return nullptr; }
+    nq->proxy = native_queue_is_proxy(nq->q);
+    nq->widx = hsa_queue_load_write_index_relaxed(nq->q);
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, NATIVE_RING_BYTES, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); (void)hsa_queue_destroy(nq->q); delete nq; return nullptr; }
     nq->ring = static_cast<uint8_t*>(p); nq->ring_bytes = NATIVE_RING_BYTES;
@@ -194,19 +248,34 @@ void native_queue_close(mirhi::NativeQueue* nq) {
     delete nq;
 }
 
-// every packet written to the queue so far has completed (a barrier packet with a completion signal, waited for on the host)
-// Waits until a completion signal reads 0 (or `timeout_ns` has passed: false).  A frame's fence is due within microseconds: poll the word in host
-// memory for 200 us, then block in the runtime (interrupt-driven, in slices of at most 10 ms so that a timeout is honoured) -- a thread that waits
-// for seconds of GPU work must not keep a core spinning.
-bool native_signal_wait(hsa_signal_t sig, uint64_t timeout_ns) {
+void native_mark_lost(mirhi::NativeDevice* nd, const char* where, const mirhi::NativeQueue* nq) {
+    if (nd->lost.exchange(true)) return;
+    char buf[320];
+    if (nq) snprintf(buf, sizeof buf, "%s: no progress within %.1f s (queue write index %llu, read index %llu%s)", where, (double)nd->timeout_ns * 1e-9,
+                     (unsigned long long)nq->widx, (unsigned long long)hsa_queue_load_read_index_relaxed(nq->q), nq->proxy ? ", intercepted queue" : "");
+    else snprintf(buf, sizeof buf, "%s: no progress within %.1f s", where, (double)nd->timeout_ns * 1e-9);
+    nd->lost_why = buf;
+    fprintf(stderr, "mirhi: device lost: %s\n", buf);
+}
+
+// Waits until a completion signal reads 0.  Returns 0 done, 1 the caller's timeout expired, 2 device lost.  A frame's fence is due within
+// microseconds: poll the word in host memory for 200 us, then block in the runtime (interrupt-driven, in slices of at most 10 ms so that a timeout
+// is honoured) -- a thread that waits for seconds of GPU work must not keep a core spinning.  NO wait is unbounded: whatever the caller's timeout,
+// when `watch`'s read index has not moved for the device's deadline (MIRHI_NATIVE_TIMEOUT_MS, 10 s) the device is marked lost -- a GPU that stopped
+// consuming packets, or a tool between this library and the queue that does something else with them, becomes an error, never a hung thread.
+int native_signal_wait(hsa_signal_t sig, uint64_t timeout_ns, mirhi::NativeDevice* nd, const mirhi::NativeQueue* watch, const char* where) {
     static const uint64_t ticks_per_s = [] { uint64_t f = 0; return hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &f) == HSA_STATUS_SUCCESS && f ? f : 100000000ull; }();
+    if (nd && nd->lost.load(std::memory_order_acquire)) return hsa_signal_load_scacquire(sig) == 0 ? 0 : 2;
     const auto t0 = std::chrono::steady_clock::now();
+    uint64_t progress_at = 0, last_ridx = watch ? hsa_queue_load_read_index_relaxed(watch->q) : 0;
     for (uint32_t it = 0;; it++) {
-        if (hsa_signal_load_scacquire(sig) == 0) return true;
+        if (hsa_signal_load_scacquire(sig) == 0) return 0;
         cpu_relax();
         if ((it & 1023u) != 1023u) continue;
         const uint64_t elapsed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (timeout_ns != UINT64_MAX && elapsed >= timeout_ns) return false;
+        if (timeout_ns != UINT64_MAX && elapsed >= timeout_ns) return 1;
+        if (watch) { const uint64_t r = hsa_queue_load_read_index_relaxed(watch->q); if (r != last_ridx) { last_ridx = r; progress_at = elapsed; } }
+        if (nd && elapsed - progress_at >= nd->timeout_ns) { native_mark_lost(nd, where, watch); return 2; }
         if (elapsed >= 200000ull) {
             uint64_t slice_ns = 10000000ull;
             if (timeout_ns != UINT64_MAX && timeout_ns - elapsed < slice_ns) slice_ns = timeout_ns - elapsed;
@@ -215,23 +284,61 @@ bool native_signal_wait(hsa_signal_t sig, uint64_t timeout_ns) {
     }
 }
 
-void native_queue_drain(mirhi::NativeQueue* nq) {
-    if (!nq) return;
-    std::lock_guard<std::mutex> qlock(nq->mu);
-    if (nq->drained == nq->widx) return;
-    while (nq->widx - hsa_queue_load_read_index_relaxed(nq->q) >= NATIVE_QUEUE_PACKETS - 2) cpu_relax();
+// Room for one more packet.  Kernel arguments: packet w uses slot w % SLOTS of the ring.  Every packet of this queue carries the barrier bit, so once the
+// packet processor has CONSUMED packet j + 1 (read index >= j + 2), packet j has finished and its slot is free: at most SLOTS - 2 packets may be outstanding
+// when slot w % SLOTS is written again.  On an intercepted queue the read index says "copied by the tool", nothing about the hardware (native_queue_is_proxy):
+// there the queue is drained every SLOTS / 2 packets instead.  The wait is bounded: a read index that stands still for the device's deadline = device lost.
+bool native_queue_drain_locked(mirhi::NativeQueue* nq);
+bool native_reserve(mirhi::NativeQueue* nq) {
+    mirhi::NativeDevice* nd = nq->nd;
+    constexpr uint64_t SLOTS = NATIVE_RING_BYTES / NATIVE_KERNARG_SLOT;
+    static_assert(SLOTS >= 64 && SLOTS <= NATIVE_QUEUE_PACKETS, "kernarg ring");
+    if (nd->lost.load(std::memory_order_acquire)) return false;
+    if (nq->proxy) { if (nq->widx - nq->drained >= SLOTS / 2) return native_queue_drain_locked(nq); return true; }
+    if (nq->widx - hsa_queue_load_read_index_scacquire(nq->q) <= SLOTS - 2) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t last = hsa_queue_load_read_index_relaxed(nq->q), progress_ns = 0;
+    for (uint32_t spins = 1;; spins++) {          // (back-pressure of a full queue: the producer yields)
+        const uint64_t r = hsa_queue_load_read_index_scacquire(nq->q);
+        if (nq->widx - r <= SLOTS - 2) return true;
+        cpu_relax();
+        if ((spins & 4095u) != 0u) continue;
+        std::this_thread::yield();
+        const uint64_t elapsed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (r != last) { last = r; progress_ns = elapsed; }
+        if (elapsed - progress_ns >= nd->timeout_ns) { native_mark_lost(nd, "waiting for room in an AQL queue", nq); return false; }
+    }
+}
+// Publishes the packet at index nq->widx whose body has been written: header (release), write index, doorbell -- the order ROCr documents for a
+// single-producer queue (the index was reserved by this one producer: nq->mu).
+void native_publish(mirhi::NativeQueue* nq, void* packet, uint16_t header, uint16_t setup) {
+    __atomic_store_n(reinterpret_cast<uint32_t*>(packet), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);     // (also orders the kernarg stores: x86 stores stay in order)
+    const uint64_t idx = nq->widx++;
+    hsa_queue_store_write_index_screlease(nq->q, idx + 1);
+    __builtin_ia32_sfence();                                     // the write-combined kernarg stores leave the CPU before the doorbell does
+    hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)idx);
+}
+
+// every packet written to the queue so far has completed (a barrier packet with a completion signal, waited for on the host); false: device lost
+bool native_queue_drain_locked(mirhi::NativeQueue* nq) {
+    if (nq->drained == nq->widx) return !nq->nd->lost.load(std::memory_order_acquire);
+    if (nq->nd->lost.load(std::memory_order_acquire)) return false;
+    // (ring room: NATIVE_QUEUE_PACKETS is four times the packets native_reserve lets be outstanding)
     hsa_signal_store_relaxed(nq->drain_sig, 1);
     auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(nq->q->base_address) + (nq->widx & (NATIVE_QUEUE_PACKETS - 1));
-    memset(reinterpret_cast<uint8_t*>(p) + 2, 0, sizeof *p - 2);
+    memset(reinterpret_cast<uint8_t*>(p) + 4, 0, sizeof *p - 4);
     p->completion_signal = nq->drain_sig;
     const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);
-    nq->widx++;
-    hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
-    hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)(nq->widx - 1));
-    (void)native_signal_wait(nq->drain_sig, UINT64_MAX);
+    native_publish(nq, p, header, 0);
+    if (native_signal_wait(nq->drain_sig, UINT64_MAX, nq->nd, nq, "draining an AQL queue") != 0) return false;
     nq->drained = nq->widx;
+    return true;
+}
+bool native_queue_drain(mirhi::NativeQueue* nq) {
+    if (!nq) return true;
+    std::lock_guard<std::mutex> qlock(nq->mu);
+    return native_queue_drain_locked(nq);
 }
 }  // namespace
 
@@ -262,15 +369,10 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     const size_t explicit_bytes = (args_bytes + 7) & ~(size_t)7;
     const size_t need = (std::max<size_t>(explicit_bytes + sizeof(ImplicitArgs), k->kernarg_bytes) + 63) & ~(size_t)63;
     if (need > NATIVE_KERNARG_SLOT || explicit_bytes + sizeof(ImplicitArgs) > NATIVE_KERNARG_SLOT) return hipErrorInvalidValue;
-    // Kernel arguments: packet w uses slot w % SLOTS of the ring.  Every packet of this queue carries the barrier bit, so once the packet processor has
-    // CONSUMED packet j + 1 (read index >= j + 2), packet j has finished and its slot is free: at most SLOTS - 2 packets may be outstanding when slot
-    // w % SLOTS is written again.  (Round 3's first version advanced a byte cursor and relied on "more than 1,000 dispatches per lap": with 320-byte
-    // argument blocks a lap was 819 dispatches while the queue admitted 1,022 -- harmless only because a deep queue resubmits identical arguments.)
+    if (!native_reserve(nq)) return hipErrorLaunchTimeOut;          // (device lost: reported as such by the caller)
     constexpr uint64_t SLOTS = NATIVE_RING_BYTES / NATIVE_KERNARG_SLOT;
-    static_assert(SLOTS >= 64 && SLOTS <= NATIVE_QUEUE_PACKETS, "kernarg ring");
-    for (uint32_t spins = 1; nq->widx - hsa_queue_load_read_index_scacquire(nq->q) > SLOTS - 2; spins++) { cpu_relax(); if ((spins & 4095u) == 0u) std::this_thread::yield(); }   // (back-pressure of a full queue)
     uint8_t* ka = nq->ring + (nq->widx % SLOTS) * NATIVE_KERNARG_SLOT;
-    alignas(16) uint8_t tmp[4096];
+    alignas(16) uint8_t tmp[NATIVE_KERNARG_SLOT];
     memcpy(tmp, args, args_bytes);
     if (explicit_bytes > args_bytes) memset(tmp + args_bytes, 0, explicit_bytes - args_bytes);
     ImplicitArgs im;
@@ -281,7 +383,6 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     memcpy(tmp + explicit_bytes, &im, sizeof im);
     memcpy(ka, tmp, explicit_bytes + sizeof im);             // write-combined stores over the BAR
     auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(nq->q->base_address) + (nq->widx & (NATIVE_QUEUE_PACKETS - 1));
-    p->setup = 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     p->workgroup_size_x = (uint16_t)block.x; p->workgroup_size_y = (uint16_t)block.y; p->workgroup_size_z = (uint16_t)block.z;
     p->reserved0 = 0;
     p->grid_size_x = grid.x * block.x; p->grid_size_y = grid.y * block.y; p->grid_size_z = grid.z * block.z;
@@ -296,11 +397,7 @@ hipError_t mirhi::native_enqueue(NativeQueue* nq, const void* key, dim3 grid, di
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
                             (uint16_t)(acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (uint16_t)(rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     nd->dispatches.fetch_add(1, std::memory_order_relaxed);
-    __atomic_store_n(reinterpret_cast<uint16_t*>(p), header, __ATOMIC_RELEASE);     // (also orders the kernarg stores: x86 stores stay in order, the doorbell store below flushes the write-combining buffers)
-    nq->widx++;
-    hsa_queue_store_write_index_relaxed(nq->q, nq->widx);
-    __builtin_ia32_sfence();
-    hsa_signal_store_screlease(nq->q->doorbell_signal, (hsa_signal_value_t)(nq->widx - 1));
+    native_publish(nq, p, header, 3 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
     return hipSuccess;
 }
 
@@ -339,6 +436,7 @@ struct mirhi_device {
     // native dispatch (mirhi_native.h): one AQL queue per queue lane, opened when the lane first carries a native submit
     NativeDevice* native = nullptr;
     std::vector<NativeQueue*> native_lanes;
+    bool native_on_external = false;          // mirhi_device_set_native_dispatch: lane 0 of a device made on the caller's stream dispatches natively too
     mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
     std::string deferred_msg;
     double total_ms[MIRHI_KERNEL_COUNT] = {0, 0, 0, 0};
@@ -512,11 +610,15 @@ struct mirhi_fence {
     std::atomic<bool> issued{true};   // false while its submission waits in the submit thread's queue (the event is recorded when it is issued)
     hsa_signal_t native_sig{0};       // native dispatch: completion signal of the submission's last packet (1 -> 0), polled in host memory
     bool native_wait = false;         //   the pending submission is waited for through it, not through `event`
+    NativeQueue* native_q = nullptr;  //   the queue that carries it (its read index is the progress a bounded wait watches)
     std::vector<mirhi_cmd*> cmds;  // submissions to check for device status on completion
     std::vector<uint64_t> seqs;    //   and which submission of each it was (mirhi_cmd::submit_seq)
     mirhi_result deferred = MIRHI_OK;   // status handed over by a listed command buffer that was destroyed / re-recorded since
     std::string deferred_msg;
 };
+
+// the command buffer's last submission is known to have finished
+static inline void cmd_finished(mirhi_cmd* c) { c->pending = false; }
 
 static uint32_t format_bpp(mirhi_format f) {
     switch (f) {
@@ -585,7 +687,8 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
         // native dispatch: the same kernels through our own AQL queues (mirhi_native.h); its copy of the code object has its own table
         d->native = native_device_open(ordinal);
         if (d->native->ok && !native_upload_symbol(d->native, "_ZN5mirhi10g_srgb_lutE", lut, sizeof lut)) { d->native->ok = false; d->native->why = "sRGB table symbol not found in the code object"; }
-        if (!d->native->ok && getenv("MIRHI_NATIVE_DISPATCH") && atoi(getenv("MIRHI_NATIVE_DISPATCH")) == 2) {      // (2: required -- tests that must not pass on the fallback)
+        d->native_lanes.assign(1, nullptr);
+        if (!d->native->ok && native_env().dispatch == 2) {      // (2: required -- tests that must not pass on the fallback)
             const std::string why = d->native->why;
             if (d->owns_stream) (void)hipStreamDestroy(d->stream);
             delete d->native; delete d;
@@ -606,20 +709,37 @@ static void drain_submits(mirhi_device* dev) {
     while (dev->sq_done.load(std::memory_order_acquire) < want) cpu_relax();
 }
 
+// A native wait ran into its deadline (native_mark_lost): the device is gone as far as this library can tell -- VK_ERROR_DEVICE_LOST
+static mirhi_result device_lost(mirhi_device* dev) {
+    return fail(MIRHI_ERR_DEVICE, "Vulkan error: DEVICE_LOST: %s", dev->native ? dev->native->lost_why.c_str() : "native dispatch");
+}
+static bool drain_native(mirhi_device* dev, const NativeQueue* which) {      // drains `which` if it is (still) one of the device's queues; false: device lost
+    for (NativeQueue* q : dev->native_lanes) if (q && q == which) return native_queue_drain(q);
+    return true;
+}
 static mirhi_result sync_all_lanes(mirhi_device* dev) {
     drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
-    for (NativeQueue* nq : dev->native_lanes) native_queue_drain(nq);
+    bool ok = true;
+    for (NativeQueue* nq : dev->native_lanes) ok = native_queue_drain(nq) && ok;
     for (hipStream_t st : dev->lanes) HIP_TRY(hipStreamSynchronize(st));
-    return MIRHI_OK;
+    return ok ? MIRHI_OK : device_lost(dev);
 }
-// the AQL queue of a queue lane (opened on first use); nullptr: native dispatch is not available
+// the AQL queue of a queue lane (opened on first use; native_lanes is sized with the lanes -- mirhi_device_set_queue_lanes -- so that threads that walk it
+// never see it move); nullptr: native dispatch is not available
 static NativeQueue* native_lane(mirhi_device* dev, uint32_t lane) {
-    if (!dev->native || !dev->native->ok) return nullptr;
-    if (dev->native_lanes.size() <= lane) dev->native_lanes.resize(lane + 1, nullptr);
+    if (!dev->native || !dev->native->ok || dev->native->lost.load(std::memory_order_acquire) || lane >= dev->native_lanes.size()) return nullptr;
     if (!dev->native_lanes[lane]) {
-        dev->native_lanes[lane] = native_queue_open(dev->native);
-        if (!dev->native_lanes[lane]) { dev->native->ok = false; dev->native->why = "could not open an AQL queue"; return nullptr; }
+        NativeQueue* nq = native_queue_open(dev->native);
+        if (!nq) { dev->native->ok = false; dev->native->why = "could not open an AQL queue"; return nullptr; }
+        if (nq->proxy && native_env().dispatch != 2) {
+            // A tool sits between this library and the hardware queue (rocprofv3 --pmc, anything on ROCr's queue-intercept API): its packets would be
+            // rewritten and the read index would stop meaning what the producer relies on.  The launches go through HIP, whose queues the tool expects.
+            native_queue_close(nq);
+            dev->native->ok = false; dev->native->why = "the AQL queue is intercepted by a tool (software doorbell): launches go through HIP";
+            return nullptr;
+        }
+        dev->native_lanes[lane] = nq;
     }
     return dev->native_lanes[lane];
 }
@@ -639,11 +759,15 @@ extern "C" mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t
     if (dev->lanes.size() > lanes) {
         // (a command buffer must not keep the handle of a stream that is about to go: ADVICE r2, mirhi_cmd::last_stream)
         std::lock_guard<std::mutex> lock(dev->mu);
-        for (mirhi_cmd* c : dev->cmds) { c->last_stream = nullptr; c->last_native = nullptr; c->pending = false; }
+        for (mirhi_cmd* c : dev->cmds) { c->last_stream = nullptr; c->last_native = nullptr; cmd_finished(c); }
         for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_native = nullptr; img->last_cmd = nullptr; }
     }
     while (dev->lanes.size() > lanes) { (void)hipStreamDestroy(dev->lanes.back()); dev->lanes.pop_back(); }
-    while (dev->native_lanes.size() > lanes) { native_queue_close(dev->native_lanes.back()); dev->native_lanes.pop_back(); }
+    {
+        std::lock_guard<std::mutex> lock(dev->mu);
+        while (dev->native_lanes.size() > lanes) { native_queue_close(dev->native_lanes.back()); dev->native_lanes.pop_back(); }
+        dev->native_lanes.resize(lanes, nullptr);
+    }
     while (dev->lanes.size() < lanes) {
         hipStream_t st = nullptr;
         HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1106,16 +1230,17 @@ extern "C" mirhi_result mirhi_cmd_set_queue_lane(mirhi_cmd* cmd, uint32_t lane) 
     NULL_CHECK(cmd, "command buffer");
     if (lane >= cmd->dev->lanes.size()) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: queue lane %u of %zu", lane, cmd->dev->lanes.size());
     drain_submits(cmd->dev);
-    for (NativeQueue* nq : cmd->dev->native_lanes) if (nq && nq == cmd->last_native) native_queue_drain(nq);
+    if (!drain_native(cmd->dev, cmd->last_native)) return device_lost(cmd->dev);
     if (cmd->last_stream) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
     HIP_TRY(hipStreamSynchronize(cmd->dev->lanes[cmd->lane < cmd->dev->lanes.size() ? cmd->lane : 0]));
-    cmd->pending = false;
+    cmd_finished(cmd);
     cmd->lane = lane;
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_cmd_destroy(mirhi_cmd* cmd) {
     NULL_CHECK(cmd, "command buffer");
     (void)sync_all_lanes(cmd->dev);
+    cmd_finished(cmd);
     hand_over_status(cmd);          // fences (and wait_idle) that still list this command buffer keep its device status
     { std::lock_guard<std::mutex> lock(cmd->dev->mu); auto& v = cmd->dev->cmds; v.erase(std::remove(v.begin(), v.end(), cmd), v.end()); }
     free_workspace(cmd);
@@ -1584,13 +1709,11 @@ static mirhi_result settle_pending(mirhi_cmd* cmd, bool in_submit) {
     while (!in_submit && cmd->queued.load(std::memory_order_acquire) > 0) cpu_relax();
     if (!cmd->pending) return MIRHI_OK;
     mirhi_device* dev = cmd->dev;
-    if (cmd->last_native) {
-        for (NativeQueue* nq : dev->native_lanes) if (nq == cmd->last_native) native_queue_drain(nq);
-    }
+    if (cmd->last_native && !drain_native(dev, cmd->last_native)) return device_lost(dev);
     bool live = false;
     for (hipStream_t st : dev->lanes) live |= st == cmd->last_stream;
     if (live) HIP_TRY(hipStreamSynchronize(cmd->last_stream));
-    cmd->pending = false;
+    cmd_finished(cmd);
     return MIRHI_OK;
 }
 
@@ -1645,8 +1768,10 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             cmd->ws.status_host[0] = 0; cmd->ws.status_host[1] = 0; cmd->ws.status_host[2] = 0; cmd->ws.status_host[3] = 0;
             HP(4);
         }
-        cmd->state = CMD_EXECUTABLE;
-        return MIRHI_OK;
+        if (!(cmd->ws.dirty || cmd->ws.replan || cmd->ws.grow_pool)) {      // (the status just handed over may have asked for clears or another plan: rebuild below)
+            cmd->state = CMD_EXECUTABLE;
+            return MIRHI_OK;
+        }
     }
     if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
         cmd->plan.size() == cmd->passes.size() && cmd->ws.pimage.size() >= cmd->passes.size() * 2 * sizeof(PassParams) && same_recording(cmd->passes, cmd->planned, true)) {
@@ -2089,7 +2214,7 @@ static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream
     for_each_attachment(dev, c, [&](mirhi_image* img) {
         const bool elsewhere = nq ? (img->last_native != nq && (img->last_native || img->last_stream)) : (img->last_native != nullptr || (img->last_stream && img->last_stream != stream));
         if (elsewhere && err == hipSuccess) {
-            if (img->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == img->last_native) native_queue_drain(q); }
+            if (img->last_native) { if (!drain_native(dev, img->last_native)) err = hipErrorLaunchTimeOut; }
             else {
                 bool live = false;
                 for (hipStream_t st : dev->lanes) live |= st == img->last_stream;
@@ -2103,6 +2228,7 @@ static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream
         }
         img->last_stream = nq ? nullptr : stream; img->last_native = nq; img->last_cmd = c; img->last_seq = c->submit_seq;
     });
+    if (err == hipErrorLaunchTimeOut && dev->native && dev->native->lost.load(std::memory_order_acquire)) return device_lost(dev);
     if (err != hipSuccess) return hip_fail(err, "attachment ordering across queue lanes");
     return MIRHI_OK;
 }
@@ -2207,7 +2333,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     // would load might be written by another scope of the batch), no two scopes share a colour, depth or primitive-id attachment, and
     // all command buffers sit on the first one's queue lane (so the batch keeps their order against earlier work of that lane).
     // Anything else runs command buffer by command buffer, in submission order on each lane.
-    bool batched = cmd_count >= 2 && cmd_count <= (uint32_t)MAX_BATCH && dev->profiling == 0 && !getenv("MIRHI_NO_BATCH");
+    bool batched = cmd_count >= 2 && cmd_count <= (uint32_t)MAX_BATCH && dev->profiling == 0 && !native_env().no_batch;
     for (uint32_t i = 0; batched && i < cmd_count; i++) {
         const mirhi_cmd* c = cmds[i];
         batched = c->plan.size() == 1 && raster_batchable(c->plan[0]) && c->lane == cmds[0]->lane &&
@@ -2224,7 +2350,10 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     // Native dispatch (mirhi_native.h): the submit's kernels go out as AQL packets on the lane's own queue -- when nothing of the submit
     // needs the HIP stream: no timed dispatches, no batch, no tile split (the band exchange lives on HIP streams), no ordered segment
     // (its clear is a HIP memset), every command buffer on one lane.
-    bool use_native = !batched && cmd_count >= 1 && dev->native && dev->native->ok && dev->profiling == 0 && dev->split_world == 1;
+    // A device made on the caller's stream (mirhi_device_create_on_stream) promised that lane 0's work is issued on that stream: submits to lane 0 stay in
+    // stream order (HIP launches) unless the caller opted in (mirhi_device_set_native_dispatch); lanes the library made itself are the library's.
+    bool use_native = !batched && cmd_count >= 1 && dev->native && dev->native->ok && dev->profiling == 0 && dev->split_world == 1 &&
+                      (dev->owns_stream || dev->native_on_external || cmds[0]->lane != 0u);
     for (uint32_t i = 0; use_native && i < cmd_count; i++) {
         use_native = cmds[i]->lane == cmds[0]->lane && cmds[i]->lane < dev->lanes.size();
         for (const PassParams& P : cmds[i]->plan) use_native = use_native && !P.ordered_recs;
@@ -2235,13 +2364,15 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     hipEvent_t fence_stop = nullptr;
     bool fence_attached = false;
     if (fence) fence->native_wait = false;
+    if (use_native && dev->native->lost.load(std::memory_order_acquire)) return device_lost(dev);
     if (fence && use_native) {
+        fence->native_q = nq;
         if (!fence->native_sig.handle && hsa_signal_create(0, 0, nullptr, &fence->native_sig) != HSA_STATUS_SUCCESS) return fail(MIRHI_ERR_DEVICE, "Vulkan error: hsa_signal_create for a fence failed");
         hsa_signal_store_relaxed(fence->native_sig, 1);
     }
     if (fence && !use_native) {
         if (!fence->event) HIP_TRY(hipEventCreate(&fence->event));
-        bool one_stream = cmd_count >= 1 && dev->profiling == 0 && !getenv("MIRHI_FENCE_RECORD");
+        bool one_stream = cmd_count >= 1 && dev->profiling == 0 && !native_env().fence_record;
         for (uint32_t i = 1; one_stream && i < cmd_count && !batched; i++) one_stream = cmds[i]->lane == cmds[0]->lane;
         if (one_stream) {
             const mirhi_cmd* last = cmds[cmd_count - 1];
@@ -2255,7 +2386,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
         for (uint32_t i = 0; i < cmd_count; i++) {
             mirhi_cmd* c = cmds[i];
             if (c->pending && c->last_stream && c->last_stream != stream) HIP_TRY(hipStreamSynchronize(c->last_stream));   // (its workspace may still be in use there)
-            if (c->pending && c->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
+            if (c->pending && c->last_native && !drain_native(dev, c->last_native)) return device_lost(dev);
             c->last_stream = stream; c->last_native = nullptr; c->pending = true; c->submit_seq++;
             { const mirhi_result ro = order_attachments(dev, c, stream); if (ro != MIRHI_OK) return ro; }
             if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
@@ -2277,9 +2408,9 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     for (uint32_t i = 0; !batched && i < cmd_count; i++) {
         mirhi_cmd* c = cmds[i];
         hipStream_t stream = dev->lanes[c->lane < dev->lanes.size() ? c->lane : 0];
-        if (c->pending && !use_native && c->last_native) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
+        if (c->pending && !use_native && c->last_native && !drain_native(dev, c->last_native)) return device_lost(dev);
         if (c->pending && c->last_stream && (use_native || c->last_stream != stream)) HIP_TRY(hipStreamSynchronize(c->last_stream));
-        if (c->pending && use_native && c->last_native && c->last_native != nq) { for (NativeQueue* q : dev->native_lanes) if (q == c->last_native) native_queue_drain(q); }
+        if (c->pending && use_native && c->last_native && c->last_native != nq && !drain_native(dev, c->last_native)) return device_lost(dev);
         // Frames in flight, this one included (command buffers submitted and not yet known to have finished).  The wide mesh variants trade
         // throughput for latency -- a frame alone on the chip finishes sooner (C3 raster 32 -> 25 us), four frames in flight leave each
         // other less room (C3 16.2 -> 19.8 us per frame) -- so a submit takes them only while the queue is shallow: the reference's
@@ -2304,7 +2435,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
                 tv.native = nq; tg.native = nq; tr.native = nq;
                 // the scope's first kernels see what the host wrote (parameter block, buffers uploaded since); its raster kernel publishes the frame
                 // -- when something other than this library's kernels wrote device memory since this queue last acquired at system scope
-                static const int scope_mode = getenv("MIRHI_NATIVE_SYSTEM_SCOPE") ? atoi(getenv("MIRHI_NATIVE_SYSTEM_SCOPE")) : 0;   // 1: system scope on every packet, 2: on every scope's first (A/B runs)
+                const int scope_mode = native_env().system_scope;   // 1: system scope on every packet, 2: on every scope's first (A/B runs)
                 const bool sys = scope_mode == 1;
                 const uint64_t foreign = dev->foreign_writes.load(std::memory_order_acquire);
                 const bool head_sys = sys || scope_mode == 2 || nq->seen_foreign != foreign || c->ws.foreign;
@@ -2312,6 +2443,9 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
                 tv.native_flags = (head_sys ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);
                 tg.native_flags = (((P.vs_total_slots == 0u && head_sys) || sys) ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);      // (behind a vertex kernel: that one took the acquire)
                 tr.native_flags = NATIVE_RELEASE_SYSTEM | (sys ? NATIVE_ACQUIRE_SYSTEM : 0u);
+                // small scopes: fewer triangles per geometry wave (GeometryHead::tris_per_wave) -- the chip is mostly idle, a shorter wave is a shorter frame
+                const uint32_t geo_waves = P.total_slots / (uint32_t)GEOM_THREADS;
+                tg.tris_per_wave = native_env().geom_tpw ? (uint32_t)native_env().geom_tpw : (geo_waves <= 256u ? 16u : (geo_waves <= 512u ? 32u : 64u));
             }
             // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
             // untimed: a timed dispatch completes through its own signal and does not overlap its neighbours the way an untimed one does)
@@ -2409,12 +2543,15 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
         dev->stats.last_status = c->ws.status_host[0];
         dev->stats.last_big_list = c->ws.status_host[1];
         dev->stats.last_bin_pages = c->ws.status_host[2];
-        if ((c->ws.status_host[0] & STATUS_POOL_EXHAUSTED) && !c->ws.grow_pool) {
+        // (the plan feedback below rewrites flags build_plan reads: not while the submit thread may be re-planning a queued submission of this command
+        // buffer -- the status words stay set and the next look at them, with nothing queued, acts on them)
+        const bool feedback = c->queued.load(std::memory_order_acquire) == 0;
+        if (feedback && (c->ws.status_host[0] & STATUS_POOL_EXHAUSTED) && !c->ws.grow_pool) {
             // not an error: the records went to the big list and the frame is complete; the pool is doubled in front of the next submit
             c->ws.grow_pool = true;
             if (c->ws.pool_scale < 64u) c->ws.pool_scale *= 2u;
         }
-        if (c->ws.status_host[3] & 0x80000000u) {
+        if (feedback && (c->ws.status_host[3] & 0x80000000u)) {
             // busy tiles of the scope before this one: few of them = a mesh in a part of the frame = the wide variant (and back), see Workspace::wide
             // Sixteen waves per tile are one workgroup per CU at a time: for up to ~240 busy tiles (the dancer asset: 232; raster 39 -> 30 us);
             // eight waves are two per CU: up to ~512 (the 70k-triangle sphere: 419; 32.5 -> 24.8 us, sixteen: 31.7 in two rounds).  Hysteresis
@@ -2428,7 +2565,7 @@ static mirhi_result status_of(mirhi_device* dev, mirhi_cmd* c) {
             else want = 0u;
             if (want != cur && c->ws.wide_eligible && !getenv("MIRHI_RASTER_WIDE")) { c->ws.wide = want; c->ws.replan = true; }
         }
-        if (!c->ws.spread && c->ws.xcd_tiles_last && c->ws.status_host[2] > 2u * c->ws.xcd_tiles_last) { c->ws.spread = true; c->ws.replan = true; c->ws.spread_tris = c->plan_tris; }
+        if (feedback && !c->ws.spread && c->ws.xcd_tiles_last && c->ws.status_host[2] > 2u * c->ws.xcd_tiles_last) { c->ws.spread = true; c->ws.replan = true; c->ws.spread_tris = c->plan_tris; }
         if (c->ws.status_host[0] & (STATUS_PAGE_TIMEOUT | STATUS_BIG_OVERFLOW)) c->ws.dirty = true;     // counters / page table are cleared before the next frame
         if (c->ws.status_host[0] & STATUS_PAGE_TIMEOUT)
             r = fail(MIRHI_ERR_DEVICE, "Vulkan error: rasterizer bin page was never published; frame is incomplete");
@@ -2444,7 +2581,7 @@ static mirhi_result check_status_words(mirhi_device* dev) {
     mirhi_result r = MIRHI_OK;
     for (mirhi_cmd* c : dev->unchecked) { const mirhi_result rc = status_of(dev, c); if (rc != MIRHI_OK) r = rc; }
     dev->unchecked.clear();
-    for (mirhi_cmd* c : dev->cmds) c->pending = false;       // (called with every lane synchronised)
+    for (mirhi_cmd* c : dev->cmds) cmd_finished(c);       // (called with every lane synchronised)
     for (mirhi_image* img : dev->images) { img->last_stream = nullptr; img->last_native = nullptr; img->last_cmd = nullptr; }
     if (dev->deferred != MIRHI_OK) { if (r == MIRHI_OK) { r = dev->deferred; g_last_error = dev->deferred_msg; } dev->deferred = MIRHI_OK; dev->deferred_msg.clear(); }
     return r;
@@ -2459,7 +2596,7 @@ static mirhi_result fence_complete(mirhi_fence* f) {
             const mirhi_result rc = status_of(f->dev, c); if (rc != MIRHI_OK) r = rc;
             release_attachments(f->dev, c, f->seqs[i]);
             if (c->submit_seq == f->seqs[i]) {              // (a later submission of the same command buffer is still its own fence's business)
-                c->pending = false;
+                cmd_finished(c);
                 auto& u = f->dev->unchecked;
                 u.erase(std::remove(u.begin(), u.end(), c), u.end());
             }
@@ -2487,10 +2624,19 @@ extern "C" mirhi_result mirhi_fence_wait(mirhi_fence* f, uint64_t timeout_ns) {
         return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
     }
     if (f->native_wait) {
-        // native dispatch: the completion signal of the submission's last packet, a word in host memory (1 -> 0)
-        if (!native_signal_wait(f->native_sig, timeout_ns)) return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        // native dispatch: the completion signal of the submission's last packet, a word in host memory (1 -> 0).  Bounded whatever the caller's timeout:
+        // a queue that stops making progress for the device's deadline is a lost device (VK_ERROR_DEVICE_LOST), not a thread that spins forever.
+        const int w = native_signal_wait(f->native_sig, timeout_ns, f->dev->native, f->native_q, "waiting for a fence");
+        if (w == 1) return fail(MIRHI_TIMEOUT, "Vulkan error: TIMEOUT");
+        if (w == 2) return device_lost(f->dev);
         f->native_wait = false;
         return fence_complete(f);
+    }
+    if (!f->event) {
+        // nothing was ever recorded for this submission: it failed in the submit thread before its first launch (the error is the deferred one)
+        f->pending = false;
+        if (f->deferred != MIRHI_OK) { const mirhi_result r = f->deferred; g_last_error = f->deferred_msg; f->deferred = MIRHI_OK; f->deferred_msg.clear(); f->cmds.clear(); f->seqs.clear(); return r; }
+        return fail(MIRHI_ERR_DEVICE, "Vulkan error: fence has no submission to wait for");
     }
     HIP_TRY(hipSetDevice(f->dev->ordinal));
     if (timeout_ns == UINT64_MAX) {
@@ -2523,8 +2669,8 @@ extern "C" mirhi_result mirhi_fence_reset(mirhi_fence* f) {
     if (f->pending) {   // resetting a fence that is still in flight is invalid in Vulkan; drain it first
         while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
         HIP_TRY(hipSetDevice(f->dev->ordinal));
-        if (f->native_wait) { (void)native_signal_wait(f->native_sig, UINT64_MAX); f->native_wait = false; }
-        else HIP_TRY(hipEventSynchronize(f->event));
+        if (f->native_wait) { (void)native_signal_wait(f->native_sig, UINT64_MAX, f->dev->native, f->native_q, "resetting a pending fence"); f->native_wait = false; }
+        else if (f->event) HIP_TRY(hipEventSynchronize(f->event));
         (void)fence_complete(f);
     }
     f->signaled = false;
@@ -2539,6 +2685,7 @@ extern "C" mirhi_result mirhi_fence_status(mirhi_fence* f) {
         f->native_wait = false; (void)fence_complete(f);
         return MIRHI_OK;
     }
+    if (!f->event) return MIRHI_NOT_READY;        // (a submission that failed in the submit thread: mirhi_fence_wait reports it)
     (void)hipSetDevice(f->dev->ordinal);
     hipError_t e = hipEventQuery(f->event);
     if (e == hipSuccess) { (void)fence_complete(f); return MIRHI_OK; }
@@ -2549,7 +2696,7 @@ extern "C" mirhi_result mirhi_fence_destroy(mirhi_fence* f) {
     NULL_CHECK(f, "fence");
     (void)hipSetDevice(f->dev->ordinal);
     while (!f->issued.load(std::memory_order_acquire)) cpu_relax();
-    if (f->pending && f->native_wait) (void)native_signal_wait(f->native_sig, UINT64_MAX);
+    if (f->pending && f->native_wait) (void)native_signal_wait(f->native_sig, UINT64_MAX, f->dev->native, f->native_q, "destroying a pending fence");
     else if (f->pending && f->event) (void)hipEventSynchronize(f->event);
     if (f->native_sig.handle) (void)hsa_signal_destroy(f->native_sig);
     if (f->event) (void)hipEventDestroy(f->event);
@@ -2644,6 +2791,70 @@ extern "C" mirhi_result mirhi_device_get_stats(mirhi_device* dev, mirhi_device_s
     std::lock_guard<std::mutex> lock(dev->mu);
     *out = dev->stats;
     out->native_dispatches = dev->native ? (uint32_t)dev->native->dispatches.load(std::memory_order_relaxed) : 0u;
+    out->dispatch_path = 0u;
+    if (dev->native && dev->native->ok) {
+        out->dispatch_path = 1u;
+        for (const NativeQueue* nq : dev->native_lanes) if (nq && nq->proxy) out->dispatch_path = 2u;
+    }
+    out->device_lost = dev->native && dev->native->lost.load(std::memory_order_acquire) ? 1u : 0u;
+    out->reserved = 0u;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_dispatch_path(mirhi_device* dev, char* out, uint32_t out_len) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out, "out");
+    if (out_len == 0) return MIRHI_OK;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    if (dev->native && dev->native->ok) {
+        bool proxy = false;
+        for (const NativeQueue* nq : dev->native_lanes) proxy |= nq && nq->proxy;
+        snprintf(out, out_len, "native: AQL packets on the device's own ROCr queues%s%s", proxy ? " (queue intercepted by a tool: every packet keeps its barrier bit)" : "",
+                 (!dev->owns_stream && !dev->native_on_external) ? "; lane 0 stays on the caller's HIP stream" : "");
+    } else snprintf(out, out_len, "hip: %s", dev->native ? dev->native->why.c_str() : "native dispatcher not opened");
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_set_native_dispatch(mirhi_device* dev, uint32_t enable) {
+    NULL_CHECK(dev, "device");
+    mirhi_result r = sync_all_lanes(dev);          // (a lane changes the queue it submits to: nothing may be in flight across the switch)
+    if (r != MIRHI_OK) return r;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    dev->native_on_external = enable != 0;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_measure_roundtrip(mirhi_device* dev, uint32_t lane, uint32_t reps, double* out_us) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(out_us, "out_us");
+    out_us[0] = out_us[1] = 0.0;
+    mirhi_result r = sync_all_lanes(dev);
+    if (r != MIRHI_OK) return r;
+    std::unique_lock<std::mutex> lock(dev->mu);
+    NativeQueue* nq = native_lane(dev, lane);
+    if (!nq) return fail(MIRHI_ERR_LOADING, "Loading error: native dispatch unavailable: %s", dev->native ? dev->native->why.c_str() : "not opened");
+    lock.unlock();
+    if (reps == 0) reps = 1;
+    hsa_signal_t sig;
+    if (hsa_signal_create(0, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return fail(MIRHI_ERR_DEVICE, "Vulkan error: hsa_signal_create failed");
+    for (int what = 0; what < 2; what++) {
+        double total = 0.0;
+        for (uint32_t i = 0; i < reps + 8u; i++) {
+            hsa_signal_store_relaxed(sig, 1);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (what == 0) {
+                const hipError_t e = launch_noop(nq, sig.handle);
+                if (e != hipSuccess) { (void)hsa_signal_destroy(sig); return dev->native->lost.load() ? device_lost(dev) : hip_fail(e, "noop dispatch"); }
+            } else {
+                std::lock_guard<std::mutex> qlock(nq->mu);
+                if (!native_reserve(nq)) { (void)hsa_signal_destroy(sig); return device_lost(dev); }
+                auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(nq->q->base_address) + (nq->widx & (NATIVE_QUEUE_PACKETS - 1));
+                memset(reinterpret_cast<uint8_t*>(p) + 4, 0, sizeof *p - 4);
+                p->completion_signal = sig;
+                native_publish(nq, p, (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                                      (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE), 0);
+            }
+            if (native_signal_wait(sig, UINT64_MAX, dev->native, nq, "round-trip measurement") != 0) { (void)hsa_signal_destroy(sig); return device_lost(dev); }
+            if (i >= 8u) total += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        }
+        out_us[what] = total / reps;
+    }
+    (void)hsa_signal_destroy(sig);
     return MIRHI_OK;
 }
 
@@ -2761,7 +2972,7 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
     drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
-    if (after && after->last_native) for (NativeQueue* nq : dev->native_lanes) if (nq == after->last_native) native_queue_drain(nq);     // (frames of a split go through HIP; one rendered before the split was set may not have)
+    if (after && after->last_native && !drain_native(dev, after->last_native)) return device_lost(dev);     // (frames of a split go through HIP; one rendered before the split was set may not have)
     hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
     hipStream_t stream = comm->stream;
     dev->foreign_writes++;                                   // (peers write the other bands into this frame)

@@ -186,7 +186,10 @@ struct PassParams {
 
 // Kernel arguments passed by value next to the PassParams pointer: what a wave needs before anything else, so that its
 // first dependent loads (draw table, bin counter -> bin records) hang off the kernarg load, not off a second memory hop.
-struct GeometryHead { const DrawDesc* draws; uint32_t num_draws; };
+struct GeometryHead {
+    const DrawDesc* draws; uint32_t num_draws;
+    uint32_t tris_per_wave;          // triangles a 64-lane workgroup takes: 64, or 32 / 16 for small scopes (the other lanes help with the pairs)
+};
 struct RasterHead {
     uint32_t* bin_count; const BinRec* bin_pool; uint32_t* big_count;
     uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;

@@ -501,7 +501,11 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     __shared__ uint16_t lds_owner[PAIR_MAX];
     if (MIRHI_GEOM_PRIO) __builtin_amdgcn_s_setprio(MIRHI_GEOM_PRIO);
     GSTAMP(0);
-    const uint32_t slot0 = blockIdx.x * GEOM_THREADS;
+    // H.tris_per_wave (64, 32 or 16; divides 64, and draws are padded to 64 slots, so a workgroup never straddles two draws): a small scope
+    // is a few latency-bound waves on a mostly idle chip -- with fewer triangles per wave the (triangle, tile) pairs of a wave, which all 64
+    // lanes share out among themselves (bin_triangle_pairs), take fewer rounds, and the wave's dependent chain is that much shorter.
+    const uint32_t tpw = H.tris_per_wave;
+    const uint32_t slot0 = blockIdx.x * tpw;
     uint32_t lo = 0, hi = H.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -509,6 +513,7 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     }
     DrawRef D = const_draws(H.draws)[lo];
     const uint32_t tri = slot0 - D.slot_base + threadIdx.x;
+    const bool has_tri = threadIdx.x < tpw && tri < D.tri_count;
     GSTAMP_SYNC(4);
     const uint32_t prim = D.prim_base + tri;
     bool valid = false;
@@ -539,7 +544,7 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
             if (threadIdx.x == 0) __hip_atomic_fetch_or(P.status, STATUS_ALPHA_TEST_TEXTURED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (tri < D.tri_count && !dropped) {
+    if (has_tri && !dropped) {
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t vidx = fetch_index(D, 3u * tri + k);
@@ -574,7 +579,7 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
         }
     }
     GSTAMP_SYNC(6);
-    if (P.prim_draw && tri < D.tri_count) P.prim_draw[prim - P.first_prim] = lo;      // (several draws in the scope)
+    if (P.prim_draw && has_tri) P.prim_draw[prim - P.first_prim] = lo;      // (several draws in the scope)
     auto flat_colour = [&]() {
         if (EARLY_COLOUR && want_flat && (valid || any)) {
             // flat-shaded triangle (all three vertex colours equal): shade it once here instead of once per pixel
@@ -594,11 +599,11 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     GSTAMP(1);
     if (P.ordered_recs) {
         // ordered segment: no bins -- triangle t of the segment sits at ordered_recs[t], in primitive order by construction
-        if (tri < D.tri_count && !dropped && any == 0) {
+        if (has_tri && !dropped && any == 0) {
             uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
             if (valid) store_tri(slot, t);
             else { slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u); }   // empty pixel box
-        } else if (tri < D.tri_count && dropped) {
+        } else if (has_tri && dropped) {
             uint4* slot = reinterpret_cast<uint4*>(P.ordered_recs) + (size_t)(prim - P.ordered_first) * 3u;
             slot[0] = make_uint4(0u, 0u, 0u, 0u); slot[1] = make_uint4(0u, 0u, 0u, 0u); slot[2] = make_uint4(0u, 0u, 1u, 0u);
         }

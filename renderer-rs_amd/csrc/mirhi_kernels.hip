@@ -35,6 +35,14 @@ namespace mirhi {
 #include "mirhi_stats.hip.h"
 #include "mirhi_ordered.hip.h"
 
+// the build this code object belongs to (build.py passes the source hash to both translation units; native_device_open compares)
+#ifndef MIRHI_SOURCE_HASH
+#define MIRHI_SOURCE_HASH "unknown"
+#endif
+__device__ __attribute__((used)) char g_build_id[17] = MIRHI_SOURCE_HASH;       // (not const: a const at namespace scope is a local symbol, the loader would not find it)
+// measurement only (mirhi_device_measure_roundtrip): one wave that does nothing
+__global__ __launch_bounds__(64) void noop_kernel(uint32_t) {}
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
 // ------------------------------------------------------------------------------------------------
@@ -56,6 +64,10 @@ static inline hipError_t launch_result() { const hipError_t e = t_native_err; t_
         else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                           \
     } while (0)
 
+hipError_t launch_noop(NativeQueue* q, uint64_t signal) {
+    return native_launch(q, reinterpret_cast<const void*>(+noop_kernel), dim3(1), dim3(64), signal, NATIVE_RELEASE_SYSTEM, (uint32_t)0);
+}
+
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
     if (P.vs_total_slots == 0) return hipSuccess;
     MIRHI_LAUNCH(vertex_kernel, dim3(P.vs_total_slots / GEOM_THREADS), dim3(GEOM_THREADS), stream, t, dev_params);
@@ -64,8 +76,9 @@ hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipS
 
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {
     if (P.total_slots == 0) return hipSuccess;
-    const uint32_t blocks = P.total_slots / GEOM_THREADS;
-    const GeometryHead H = {P.draws, P.num_draws};
+    const uint32_t tpw = (t.tris_per_wave == 16u || t.tris_per_wave == 32u) ? t.tris_per_wave : (uint32_t)GEOM_THREADS;
+    const uint32_t blocks = P.total_slots / tpw;
+    const GeometryHead H = {P.draws, P.num_draws, tpw};
     // (more waves than the chip holds at five per SIMD: the occupancy-oriented variant)
     if (blocks > 5u * 1024u) MIRHI_LAUNCH(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
     else MIRHI_LAUNCH(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
@@ -152,7 +165,7 @@ hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* c
     uint32_t most = 0, total = 0;
     for (uint32_t i = 0; i < n; i++) {
         B.params[i] = dev_params[i];
-        B.head[i] = GeometryHead{P[i]->draws, P[i]->num_draws};
+        B.head[i] = GeometryHead{P[i]->draws, P[i]->num_draws, (uint32_t)GEOM_THREADS};
         B.blocks[i] = P[i]->total_slots / GEOM_THREADS;
         most = B.blocks[i] > most ? B.blocks[i] : most; total += B.blocks[i];
     }

@@ -13,7 +13,8 @@ namespace mirhi {
 // how a submit's fence is signalled (mirhi_queue_submit).
 // native: dispatch on this AQL queue instead of a HIP stream (mirhi_native.h); native_signal: an hsa_signal_t handle decremented at the
 // kernel's end (a submit's fence), 0 = none.  Never together with start / stop.
-struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; uint32_t native_flags = 0; };
+// tris_per_wave: GeometryHead::tris_per_wave (0 = 64)
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; uint32_t native_flags = 0; uint32_t tris_per_wave = 0; };
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
@@ -34,6 +35,8 @@ hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_para
 // statistics pass only: adds the number of pixels of `prim` (the scope's primitive-id image, NO_PRIM where nothing won) that hold
 // a primitive to stats[0]
 hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream);
+// measurement: one empty one-wave kernel on an AQL queue, `signal` decremented at its end (mirhi_device_measure_roundtrip)
+hipError_t launch_noop(NativeQueue* q, uint64_t signal);
 // sRGB byte -> linear table of the current device (R8G8B8A8_SRGB textures); 256 floats
 hipError_t upload_srgb_lut(const float* lut, hipStream_t stream);   // asynchronous: the caller synchronises `stream`
 }  // namespace mirhi

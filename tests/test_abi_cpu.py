@@ -23,8 +23,8 @@ def test_library_exports_every_declared_symbol(mirhi):
     assert len(declared_functions()) >= 60
     # the ctypes binding covers the same set
     assert set(mirhi._SIGNATURES) == set(declared_functions())
-    assert mirhi.lib().mirhi_abi_version() == 4 == mirhi.ABI_VERSION      # (the binding refuses a library of another ABI at load)
-    assert int(re.search(r"#define MIRHI_ABI_VERSION (\d+)u", HEADER).group(1)) == 4
+    assert mirhi.lib().mirhi_abi_version() == 5 == mirhi.ABI_VERSION      # (the binding refuses a library of another ABI at load)
+    assert int(re.search(r"#define MIRHI_ABI_VERSION (\d+)u", HEADER).group(1)) == 5
 
 
 def test_every_entry_point_cites_the_reference():
