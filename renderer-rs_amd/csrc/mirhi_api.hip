@@ -1927,7 +1927,10 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     if ((r = grow(&w.big_recs, &w.big_recs_bytes, (max_big ? max_big : 1) * sizeof(BigRec))) != MIRHI_OK) return r;
     {
         size_t counter_bytes = w.counters_words * 4;
-        const size_t want_words = CTR_BINS + 8 * max_tiles;   // fixed words (big-list and pool counters), then the bin counters (one per tile, or per tile and XCD)
+        bool any_xcd_bins = false;
+        for (const Geo& g : geo) any_xcd_bins |= g.xcd_bins;
+        // fixed words (big-list and pool counters), then the bin counters: one per tile -- per tile and XCD in scopes with per-XCD bins -- 64 bytes apart
+        const size_t want_words = CTR_BINS + (any_xcd_bins ? 8 : 1) * max_tiles * (size_t)BIN_COUNT_STRIDE;
         const bool had = w.counters && counter_bytes >= want_words * 4;
         if ((r = grow(&w.counters, &counter_bytes, want_words * 4)) != MIRHI_OK) return r;
         w.counters_words = counter_bytes / 4;
@@ -2443,7 +2446,8 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
                 tv.native_flags = (head_sys ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);
                 tg.native_flags = (((P.vs_total_slots == 0u && head_sys) || sys) ? NATIVE_ACQUIRE_SYSTEM : 0u) | (sys ? NATIVE_RELEASE_SYSTEM : 0u);      // (behind a vertex kernel: that one took the acquire)
                 tr.native_flags = NATIVE_RELEASE_SYSTEM | (sys ? NATIVE_ACQUIRE_SYSTEM : 0u);
-                // small scopes: fewer triangles per geometry wave (GeometryHead::tris_per_wave) -- the chip is mostly idle, a shorter wave is a shorter frame
+            }
+            {   // small scopes: fewer triangles per geometry wave (GeometryHead::tris_per_wave) -- the chip is mostly idle, a shorter wave is a shorter frame
                 const uint32_t geo_waves = P.total_slots / (uint32_t)GEOM_THREADS;
                 tg.tris_per_wave = native_env().geom_tpw ? (uint32_t)native_env().geom_tpw : (geo_waves <= 256u ? 16u : (geo_waves <= 512u ? 32u : 64u));
             }

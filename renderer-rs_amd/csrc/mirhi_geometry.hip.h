@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t reserve_bin_slots(ParamsRef P, bool act, uin
         rem &= ~grp;
     }
     uint32_t raw = 0;
-    if (gsize) raw = atomicAdd(&P.bin_count[xcd * P.count_stride + tile], gsize);
+    if (gsize) raw = atomicAdd(&P.bin_count[(xcd * P.count_stride + tile) * BIN_COUNT_STRIDE], gsize);
     return raw;
 }
 

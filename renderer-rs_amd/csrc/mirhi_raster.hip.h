@@ -670,14 +670,14 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
     // (the head of the parameters comes by value: the counter loads depend on the kernarg load alone, not on a second hop)
     __shared__ uint32_t lds_seg[(TEAMS > 1 || WIDE) ? 9 : 1];     // two-team and wide variants: records in the per-XCD sub-bins before k; [8] = all
     const bool xcd_bins = (TEAMS > 1 || WIDE) && H.count_stride != 0u;
-    uint32_t count_raw = H.bin_count[tile];
+    uint32_t count_raw = H.bin_count[tile * BIN_COUNT_STRIDE];
     const uint32_t nbig_raw = *H.big_count;
     if (TEAMS > 1 || WIDE) {
         if (xcd_bins) {
             if (threadIdx.x == 0) {
                 uint32_t c[8];
 #pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) c[k] = H.bin_count[k * H.count_stride + tile];
+                for (uint32_t k = 0; k < 8u; k++) c[k] = H.bin_count[(k * H.count_stride + tile) * BIN_COUNT_STRIDE];
                 uint32_t acc = 0;
 #pragma unroll
                 for (uint32_t k = 0; k < 8u; k++) { lds_seg[k] = acc; acc += c[k] < H.sub_cap ? c[k] : H.sub_cap; }
@@ -778,8 +778,8 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
                                                          qbit0, tid, lane);
     STAMP(2);
     if (count && tid == 0 && team == 0) {                        // ready for the next scope that uses this workspace
-        H.bin_count[tile] = 0;
-        if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[k * H.count_stride + tile] = 0;
+        H.bin_count[tile * BIN_COUNT_STRIDE] = 0;
+        if (xcd_bins) for (uint32_t k = 1; k < 8u; k++) H.bin_count[(k * H.count_stride + tile) * BIN_COUNT_STRIDE] = 0;
     }
     // (the row was copied to LDS before the first barrier of the bin pass; the next geometry kernel comes behind this kernel)
     if (need_pages && threadIdx.x < (uint32_t)BIN_TABLE_ROW) launder_params((ParamsPtr)(uintptr_t)params)->bin_table[tile * (uint32_t)BIN_TABLE_ROW + threadIdx.x] = PAGE_EMPTY;

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     const uint4* pool = reinterpret_cast<const uint4*>(H.bin_pool);
     const uint32_t nsub = H.count_stride ? 8u : 1u;
     for (uint32_t k = 0; k < nsub; k++) {
-        const uint32_t raw = H.bin_count[k * H.count_stride + tile];
+        const uint32_t raw = H.bin_count[(k * H.count_stride + tile) * BIN_COUNT_STRIDE];
         const uint32_t cnt = raw < H.sub_cap ? raw : H.sub_cap;
         for (uint32_t j = tid; j < cnt; j += RASTER_THREADS) {
             const uint32_t page = j < H.fixed_recs ? (tile * H.fixed_recs + j) >> BIN_PAGE_LOG2 : P.bin_table[tile * (uint32_t)BIN_TABLE_ROW + k * 8u + (j >> BIN_PAGE_LOG2)];

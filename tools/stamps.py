@@ -40,9 +40,11 @@ print(f"  wave start spread: p50 {us(np.median(s[:,0]-t0)):.2f} us, max {us((s[:
 buf = np.zeros(16384 * 8, dtype=np.uint64)
 L.mirhi_debug_read_geo_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
 g = buf.reshape(-1, 8).astype(np.int64)
-nb = min(16384, (scene.num_triangles + 63) // 64)
+waves64 = (scene.num_triangles + 63) // 64
+tpw = int(os.environ.get("MIRHI_GEOM_TPW", "0")) or (16 if waves64 <= 256 else (32 if waves64 <= 512 else 64))      # (the host's choice: submit_now)
+nb = min(16384, (scene.num_triangles + tpw - 1) // tpw)
 g = g[:nb]; g = g[g[:, 3] > 0]
-print(f"geometry waves sampled {len(g)}")
+print(f"geometry waves sampled {len(g)} ({tpw} triangles per wave): kernel span {us(g[:,3].max() - g[:,0].min()):.2f} us (first start -> last end), wave start spread p50 {us(np.median(g[:,0] - g[:,0].min())):.2f} max {us((g[:,0] - g[:,0].min()).max()):.2f} us")
 for name, a, b in (("  entry -> draw descriptor in registers", 0, 4), ("  -> indices + vertices in registers", 4, 5), ("  -> setup done", 5, 6), ("  -> flat colour stored", 6, 1),
                    ("fetch + vs + setup", 0, 1), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
     d = g[:, b] - g[:, a]
