@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define MIRHI_ABI_VERSION 5u     /* 3: mirhi_pipeline_desc.fragment_discard_enable; 4: mirhi_device_set_submit_thread; 5: mirhi_device_set_native_dispatch,
-                                    mirhi_device_dispatch_path, mirhi_device_measure_roundtrip, mirhi_build_id, mirhi_device_stats grew four words */
+                                    mirhi_device_dispatch_path, mirhi_device_measure_roundtrip, mirhi_build_id, mirhi_device_set_tile_split_layout,
+                                    mirhi_device_split_rows, mirhi_device_stats grew four words */
 
 /* ---- errors: one code per RhiError variant (crates/rhi/src/error.rs:6-50) ------------------------ */
 typedef int32_t mirhi_result;
@@ -73,9 +74,18 @@ mirhi_result mirhi_device_wait_idle(mirhi_device* dev);                   /* Dev
                                                                              status of frames submitted without a fence, as mirhi_fence_wait does */
 mirhi_result mirhi_device_destroy(mirhi_device* dev);                     /* fails if children are alive */
 mirhi_result mirhi_device_name(mirhi_device* dev, char* out, uint32_t out_len);
-/* screen-tile-row split: this device rasterizes only tile rows owned by `rank` of `world`
- * (contiguous bands); rank 0 / world 1 = whole frame.  Gathering the bands is the caller's collective. */
+/* screen-tile-row split: this device rasterizes only the tile rows owned by `rank` of `world` (which ones: the
+ * layout below); rank 0 / world 1 = whole frame.  Gathering the rows is mirhi_comm_all_gather_bands, or the caller's collective. */
 mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t rank, uint32_t world);
+/* Which tile rows a rank gets.  BANDS: one contiguous band of ceil(tile rows / world) rows per rank (the last rank's may be short).  INTERLEAVED (the
+ * default; MIRHI_SPLIT=bands|interleaved in the environment sets another default): rank r owns tile rows r, r + world, r + 2 world, ... -- every rank then
+ * holds the same share of every part of the frame, so the slowest rank is the average one whatever the scene puts where ("interleave bands").
+ * Every rank of a communicator must use the same layout; set it before mirhi_device_set_tile_split / mirhi_comm_create. */
+typedef enum { MIRHI_SPLIT_BANDS = 0, MIRHI_SPLIT_INTERLEAVED = 1 } mirhi_split_layout;
+mirhi_result mirhi_device_set_tile_split_layout(mirhi_device* dev, mirhi_split_layout layout);
+/* the tile rows (32 pixel rows each, the last one of a frame possibly short) this device rasterizes of a frame `height` pixels high:
+ * rows first_tile_row + k * tile_row_step, k = 0 .. tile_rows - 1 */
+mirhi_result mirhi_device_split_rows(mirhi_device* dev, uint32_t height, uint32_t* first_tile_row, uint32_t* tile_row_step, uint32_t* tile_rows);
 /* frames in flight (crates/renderer/src/lib.rs:43 MAX_FRAMES_IN_FLIGHT): command buffers are assigned round-robin to
  * `lanes` submit streams at creation, so independent frames (own command buffer, own target) overlap on the GPU the way
  * the reference's per-frame command buffers do between their semaphores.  Default 1 = strict submission order.  Set before
@@ -88,7 +98,8 @@ mirhi_result mirhi_device_set_queue_lanes(mirhi_device* dev, uint32_t lanes);
  * a resource first wait until all queued submissions have been issued; an error the launches raise is reported by the submission's
  * fence (or by wait_idle if it has none).  Submissions are issued in the order they were made. */
 mirhi_result mirhi_device_set_submit_thread(mirhi_device* dev, uint32_t enable);
-/* first/last+1 pixel row of the band rendered by this device for a target of `height` rows */
+/* first/last+1 pixel row of the band rendered by this device for a target of `height` rows (MIRHI_SPLIT_BANDS; with interleaved rows there is no single band:
+ * InvalidHandle -- use mirhi_device_split_rows) */
 mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end);
 
 /* ---- buffers: BufferUsage + Buffer (buffer.rs:47-112,149-293,345-417) ------------------------------ */
@@ -358,9 +369,9 @@ typedef enum {
                                      (4K BGRA8 on 8 GPUs: 4.15 MB per link) where a ring would pass 7 hops one after another */
     MIRHI_GATHER_BROADCAST = 1    /* one grouped batch of `world` in-place ncclBroadcast, one band each; RCCL picks the algorithm */
 } mirhi_gather_algo;
-/* In place on `frame` (a colour image every rank created with the same extent and format): rank r's rows
- * [band_begin(r), band_end(r)) -- mirhi_device_band_rows -- are sent, the other bands received.  Bands may differ in size (the last
- * one is short when the tile rows do not divide).  Enqueued on the queue lane of `after` (the command buffer that rendered the
+/* In place on `frame` (a colour image every rank created with the same extent and format): the rows this rank rendered -- its band, or with interleaved
+ * rows one 32-row piece per tile row it owns (mirhi_device_split_rows) -- are sent, the other ranks' rows received, all pieces in ONE RCCL group.  Shares may
+ * differ in size (the last band / tile row is short when the rows do not divide).  Enqueued on the queue lane of `after` (the command buffer that rendered the
  * frame; NULL = lane 0), so it runs behind that frame's raster kernel; completion through mirhi_device_wait_idle or a later
  * submit on the same lane. */
 mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_image* frame, mirhi_cmd* after, mirhi_gather_algo algo);

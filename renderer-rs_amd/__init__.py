@@ -102,6 +102,12 @@ class GatherAlgo:
     DIRECT, BROADCAST = range(2)
 
 
+class SplitLayout:
+    """mirhi_split_layout: which tile rows a rank of a tile split rasterizes"""
+    BANDS, INTERLEAVED = range(2)
+    NAMES = {"bands": 0, "interleaved": 1}
+
+
 ABI_VERSION = 5                 # MIRHI_ABI_VERSION of include/mirhi.h this file mirrors
 COMM_ID_BYTES = 128
 
@@ -180,6 +186,8 @@ _SIGNATURES = {
     "mirhi_device_set_queue_lanes": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_set_submit_thread": (C.c_int32, [C.c_void_p, C.c_uint32]),
     "mirhi_device_band_rows": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mirhi_device_set_tile_split_layout": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mirhi_device_split_rows": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mirhi_buffer_create": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mirhi_buffer_create_with_data": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mirhi_buffer_write": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
@@ -312,8 +320,21 @@ class Device:
         check(lib().mirhi_device_name(self.handle, buf, 256))
         return buf.value.decode()
 
-    def set_tile_split(self, rank: int, world: int):
+    def set_tile_split(self, rank: int, world: int, layout=None):
+        """layout: None = keep the device's (default interleaved, MIRHI_SPLIT in the environment), SplitLayout.* or 'bands' / 'interleaved'"""
+        if layout is not None:
+            check(lib().mirhi_device_set_tile_split_layout(self.handle, SplitLayout.NAMES[layout] if isinstance(layout, str) else int(layout)))
         check(lib().mirhi_device_set_tile_split(self.handle, rank, world))
+
+    def set_split_layout(self, layout):
+        """SplitLayout.* or 'bands' / 'interleaved' (mirhi_device_set_tile_split_layout): before set_tile_split / Comm"""
+        check(lib().mirhi_device_set_tile_split_layout(self.handle, SplitLayout.NAMES[layout] if isinstance(layout, str) else int(layout)))
+
+    def split_rows(self, height: int):
+        """(first tile row, step, number of tile rows) this device rasterizes of a frame `height` pixels high"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib().mirhi_device_split_rows(self.handle, height, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_queue_lanes(self, lanes: int):
         check(lib().mirhi_device_set_queue_lanes(self.handle, lanes))

@@ -420,6 +420,7 @@ struct mirhi_device {
     // open with an agent-scope one (tools/microbench/hsa/stale.cpp: no stale word after any such write even without -- kept as the rule)
     std::atomic<uint64_t> foreign_writes{1};
     uint32_t split_rank = 0, split_world = 1;
+    uint32_t split_layout = MIRHI_SPLIT_INTERLEAVED;   // mirhi_device_set_tile_split_layout (MIRHI_SPLIT=bands|interleaved sets the default)
     uint32_t profiling = 0;                  // MIRHI_PROFILE_* bits
     std::mutex mu;
     std::vector<TimedDispatch> pending;       // timed dispatches not yet read back
@@ -583,7 +584,7 @@ struct mirhi_cmd {
     // (renderer.rs:452-557); end() then finds plan, workspace and parameter block as they are and touches nothing.
     std::vector<RecordedPass> planned;
     bool plan_valid = false;
-    uint32_t plan_split_rank = 0, plan_split_world = 1;
+    uint32_t plan_split_rank = 0, plan_split_world = 1, plan_split_layout = 0;
     // current bindings (dynamic state + descriptors)
     mirhi_pipeline* pipeline = nullptr;
     mirhi_buffer* vb = nullptr; uint64_t vb_offset = 0;
@@ -656,6 +657,7 @@ static mirhi_result device_create_common(int32_t ordinal, void* stream, bool ext
     mirhi_device* d = new (std::nothrow) mirhi_device();
     if (!d) return fail(MIRHI_ERR_ALLOCATOR, "Allocator error: host allocation failed");
     d->ordinal = ordinal;
+    if (const char* sp = getenv("MIRHI_SPLIT")) d->split_layout = strcmp(sp, "bands") == 0 ? (uint32_t)MIRHI_SPLIT_BANDS : (uint32_t)MIRHI_SPLIT_INTERLEAVED;
     snprintf(d->name, sizeof d->name, "%s (%s)", prop.name, prop.gcnArchName);
     if (external) { d->stream = (hipStream_t)stream; d->owns_stream = false; }
     else {
@@ -809,28 +811,46 @@ extern "C" mirhi_result mirhi_device_set_tile_split(mirhi_device* dev, uint32_t 
     dev->split_rank = rank; dev->split_world = world;
     return MIRHI_OK;
 }
-static void band_tile_rows(uint32_t rank, uint32_t world, uint32_t tiles_y, uint32_t* r0, uint32_t* r1) {
-    const uint32_t per = (tiles_y + world - 1) / world;   // contiguous bands, last rank short
-    uint32_t b = rank * per, e = b + per;
-    if (b > tiles_y) b = tiles_y;
-    if (e > tiles_y) e = tiles_y;
-    *r0 = b; *r1 = e;
+// The tile rows of a frame of `tiles_y` rows that `rank` of `world` rasterizes: rows first + k * step, k < count (PassParams::tile_row_*).
+//   bands        one contiguous band per rank, ceil(tiles_y / world) rows, the last rank short: step 1
+//   interleaved  rank r owns rows r, r + world, r + 2 world, ...: every rank gets the same share of every part of the frame, whatever the scene puts where
+//                (SURVEY 8e's load-balance option; C5 in eight bands: 71 | 72 | 70 | 66 | 53 | 24 | 11 | 5 us of raster -- the slowest rank sets the frame)
+static void split_rows(uint32_t layout, uint32_t rank, uint32_t world, uint32_t tiles_y, uint32_t* first, uint32_t* step, uint32_t* count) {
+    if (world <= 1) { *first = 0; *step = 1; *count = tiles_y; return; }
+    if (layout == MIRHI_SPLIT_BANDS) {
+        const uint32_t per = (tiles_y + world - 1) / world;
+        uint32_t b = rank * per, e = b + per;
+        if (b > tiles_y) b = tiles_y;
+        if (e > tiles_y) e = tiles_y;
+        *first = b; *step = 1; *count = e - b;
+        return;
+    }
+    *first = rank; *step = world; *count = rank < tiles_y ? (tiles_y - rank + world - 1) / world : 0u;
+}
+extern "C" mirhi_result mirhi_device_set_tile_split_layout(mirhi_device* dev, mirhi_split_layout layout) {
+    NULL_CHECK(dev, "device");
+    if (layout != MIRHI_SPLIT_BANDS && layout != MIRHI_SPLIT_INTERLEAVED) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: unknown tile split layout %d", (int)layout);
+    drain_submits(dev);
+    dev->split_layout = (uint32_t)layout;
+    return MIRHI_OK;
+}
+extern "C" mirhi_result mirhi_device_split_rows(mirhi_device* dev, uint32_t height, uint32_t* first_tile_row, uint32_t* tile_row_step, uint32_t* tile_rows) {
+    NULL_CHECK(dev, "device"); NULL_CHECK(first_tile_row, "first_tile_row"); NULL_CHECK(tile_row_step, "tile_row_step"); NULL_CHECK(tile_rows, "tile_rows");
+    split_rows(dev->split_layout, dev->split_rank, dev->split_world, (height + TILE - 1) / TILE, first_tile_row, tile_row_step, tile_rows);
+    return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_device_band_rows(mirhi_device* dev, uint32_t height, uint32_t* row_begin, uint32_t* row_end) {
     NULL_CHECK(dev, "device"); NULL_CHECK(row_begin, "row_begin"); NULL_CHECK(row_end, "row_end");
-    const uint32_t tiles_y = (height + TILE - 1) / TILE;
-    uint32_t r0, r1;
-    band_tile_rows(dev->split_rank, dev->split_world, tiles_y, &r0, &r1);
-    uint32_t p0 = r0 * TILE, p1 = r1 * TILE;
+    if (dev->split_world > 1 && dev->split_layout != MIRHI_SPLIT_BANDS)
+        return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split is interleaved (no single band of rows): use mirhi_device_split_rows");
+    uint32_t first, step, count;
+    split_rows(MIRHI_SPLIT_BANDS, dev->split_rank, dev->split_world, (height + TILE - 1) / TILE, &first, &step, &count);
+    uint32_t p0 = first * TILE, p1 = (first + count) * TILE;
     if (p0 > height) p0 = height;
     if (p1 > height) p1 = height;
     *row_begin = p0; *row_end = p1;
     return MIRHI_OK;
 }
-
-// ------------------------------------------------------------------------------------------------
-// buffers (buffer.rs)
-// ------------------------------------------------------------------------------------------------
 static const char* usage_name(mirhi_buffer_usage u) {
     static const char* names[] = {"vertex", "index", "uniform", "storage", "staging", "indirect"};
     return (u >= 0 && u <= 5) ? names[u] : "unknown";
@@ -1753,7 +1773,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
     REQUIRE_RECORDING(cmd);
     if (cmd->in_rendering) return fail(MIRHI_ERR_DEVICE, "Vulkan error: end() inside an active rendering scope");
     mirhi_device* dev = cmd->dev;
-    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
+    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world && cmd->plan_split_layout == dev->split_layout &&
         same_recording(cmd->passes, cmd->planned)) {
         HP(0);
         // The frame recorded last time, recorded again: plan, workspace and parameter block are what they have to be.  No HIP call,
@@ -1773,7 +1793,7 @@ extern "C" mirhi_result mirhi_cmd_end(mirhi_cmd* cmd) {
             return MIRHI_OK;
         }
     }
-    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world &&
+    if (cmd->plan_valid && !cmd->ws.grow_pool && !cmd->ws.replan && !cmd->ws.dirty && cmd->plan_split_rank == dev->split_rank && cmd->plan_split_world == dev->split_world && cmd->plan_split_layout == dev->split_layout &&
         cmd->plan.size() == cmd->passes.size() && cmd->ws.pimage.size() >= cmd->passes.size() * 2 * sizeof(PassParams) && same_recording(cmd->passes, cmd->planned, true)) {
         // The same frame into another swapchain image: the plan stands, PassParams::color of every scope is rewritten (host copy, both parities in the parameter block).
         mirhi_result r = settle_pending(cmd);                  // (the block is read by a submission that is still pending: wait for it -- a fenced loop has)
@@ -1867,13 +1887,13 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         if (cmd->ws.spread && (tris_now > 2 * cmd->ws.spread_tris || 2 * tris_now < cmd->ws.spread_tris)) cmd->ws.spread = false;
     }
     size_t total_draws = 0, max_tiles = 0, max_pages = 0, max_big = 0;
-    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };
+    struct Geo { uint32_t tiles_x, tiles_y, r0, r1, rstep, bin_cap, sub_cap, big_cap, fixed_pages, fixed_per_tile; bool xcd_bins; };      // r0 / r1 / rstep: PassParams::tile_row_begin / _end / _step
     std::vector<Geo> geo;
     for (auto& pass : cmd->passes) {
         const RecordedPass::Target& ci = pass.color_t;
         Geo g;
         g.tiles_x = (ci.width + TILE - 1) / TILE; g.tiles_y = (ci.height + TILE - 1) / TILE;
-        band_tile_rows(dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.r1);
+        { uint32_t count; split_rows(dev->split_layout, dev->split_rank, dev->split_world, g.tiles_y, &g.r0, &g.rstep, &count); g.r1 = g.r0 + count; }
         const size_t tiles = (size_t)g.tiles_x * (g.r1 - g.r0);
         const RasterMode mode = raster_mode(pass, tiles, cmd->ws.spread, cmd->ws.wide);
         g.xcd_bins = mode.xcd_bins;
@@ -2057,7 +2077,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
         PassParams P;
         memset(&P, 0, sizeof P);
         P.width = ci.width; P.height = ci.height;
-        P.tiles_x = g.tiles_x; P.tiles_y = g.tiles_y; P.tile_row_begin = g.r0; P.tile_row_end = g.r1;
+        P.tiles_x = g.tiles_x; P.tiles_y = g.tiles_y; P.tile_row_begin = g.r0; P.tile_row_end = g.r1; P.tile_row_step = g.rstep;
         P.num_draws = (uint32_t)draws.size(); P.total_tris = pass.total_tris;
         P.draws = dev_draws + draws_done;
         depth_key_setup(P, pass);
@@ -2151,7 +2171,7 @@ static mirhi_result build_plan(mirhi_cmd* cmd, bool in_submit) {
     if ((r = pblock_commit(w, stream)) != MIRHI_OK) return r;
     if (!w.pblock_direct) { cmd->last_stream = stream; cmd->last_native = nullptr; cmd->pending = true; }     // (the copy is in the lane's stream)
     { std::lock_guard<std::mutex> lk(dev->mu); cmd->planned = cmd->passes; }      // (settle_readers scans `planned` of pending command buffers under this lock)
-    cmd->plan_split_rank = dev->split_rank; cmd->plan_split_world = dev->split_world;
+    cmd->plan_split_rank = dev->split_rank; cmd->plan_split_world = dev->split_world; cmd->plan_split_layout = dev->split_layout;
     cmd->plan_valid = true;
     dev->stats.workspace_bytes = w.bytes();
     return MIRHI_OK;
@@ -2983,35 +3003,43 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
     const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;
     const size_t row_bytes = (size_t)frame->width * format_bpp(frame->format);
     Rccl* R = comm->rccl;
-    auto band = [&](uint32_t r, size_t* off, size_t* bytes) {
-        uint32_t t0, t1;
-        band_tile_rows(r, comm->world, tiles_y, &t0, &t1);
-        size_t p0 = (size_t)t0 * TILE, p1 = (size_t)t1 * TILE;
-        if (p0 > frame->height) p0 = frame->height;
-        if (p1 > frame->height) p1 = frame->height;
-        *off = p0 * row_bytes; *bytes = (p1 - p0) * row_bytes;
+    // the pieces of the frame rank r rendered: one run of pixel rows per tile row it owns (bands: the rows are adjacent and go as ONE piece; interleaved:
+    // rank r's tile rows r, r + world, ... are 32 pixel rows each, a tile row of the frame apart -- every piece is contiguous in the row-major image)
+    struct Piece { size_t off, bytes; };
+    auto pieces = [&](uint32_t r, std::vector<Piece>& out) {
+        out.clear();
+        uint32_t first, step, count;
+        split_rows(dev->split_layout, r, comm->world, tiles_y, &first, &step, &count);
+        auto run = [&](uint32_t t0, uint32_t t1) {
+            size_t p0 = (size_t)t0 * TILE, p1 = (size_t)t1 * TILE;
+            if (p0 > frame->height) p0 = frame->height;
+            if (p1 > frame->height) p1 = frame->height;
+            if (p1 > p0) out.push_back(Piece{p0 * row_bytes, (p1 - p0) * row_bytes});
+        };
+        if (step == 1) run(first, first + count);
+        else for (uint32_t k = 0; k < count; k++) run(first + k * step, first + k * step + 1);
     };
-    size_t my_off, my_bytes;
-    band(comm->rank, &my_off, &my_bytes);
+    std::vector<Piece> mine, theirs;
+    pieces(comm->rank, mine);
     if (comm->world == 1) return MIRHI_OK;
     HIP_TRY(hipEventRecord(comm->ready, lane));              // the exchange starts behind the frame's raster kernel ...
     HIP_TRY(hipStreamWaitEvent(stream, comm->ready, 0));
     RCCL_TRY(R, R->GroupStart());
     // Inside the group nothing returns early: a failing call must not leave the thread's RCCL group open (every later RCCL call of
     // this thread, torch.distributed's included, would queue into a group that never ends).  The first error is kept, the group is
-    // closed, and only a successful exchange makes the lane wait for it.
+    // closed, and only a successful exchange makes the lane wait for it.  All pieces of all peers travel in this ONE group: RCCL fuses the
+    // point-to-point transfers of a group into one launch per peer pair (interleaved 4K on 8 ranks: 8-9 pieces of 491 KB to and from each of 7 peers).
     ncclResult_t first = ncclSuccess; const char* what = "";
     auto note = [&](ncclResult_t rc, const char* call) { if (rc != ncclSuccess && first == ncclSuccess) { first = rc; what = call; } };
     for (uint32_t r = 0; r < comm->world && first == ncclSuccess; r++) {
-        size_t off, bytes;
-        band(r, &off, &bytes);
+        pieces(r, theirs);
         if (algo == MIRHI_GATHER_BROADCAST) {
-            if (bytes) note(R->Broadcast(frame->ptr + off, frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream), "ncclBroadcast");
+            for (const Piece& pc : theirs) if (first == ncclSuccess) note(R->Broadcast(frame->ptr + pc.off, frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclBroadcast");
             continue;
         }
         if (r == comm->rank) continue;
-        if (my_bytes) note(R->Send(frame->ptr + my_off, my_bytes, ncclUint8, (int)r, comm->comm, stream), "ncclSend");
-        if (bytes && first == ncclSuccess) note(R->Recv(frame->ptr + off, bytes, ncclUint8, (int)r, comm->comm, stream), "ncclRecv");
+        for (const Piece& pc : mine) if (first == ncclSuccess) note(R->Send(frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclSend");
+        for (const Piece& pc : theirs) if (first == ncclSuccess) note(R->Recv(frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclRecv");
     }
     note(R->GroupEnd(), "ncclGroupEnd");
     if (first != ncclSuccess) return fail(MIRHI_ERR_DEVICE, "Vulkan error: RCCL: %s (%s)", R->GetErrorString(first), what);

@@ -123,7 +123,10 @@ static_assert(sizeof(BinRec) == 32, "BinRec is 32 bytes");
 struct PassParams {
     uint32_t width, height;           // colour target extent
     uint32_t tiles_x, tiles_y;
-    uint32_t tile_row_begin, tile_row_end;   // band of tile rows rasterized on this device
+    // Tile rows rasterized on this device (tile-row split): rows tile_row_begin + k * tile_row_step, k = 0 .. tile_row_end - tile_row_begin - 1.
+    // One contiguous band per rank: step 1 (begin / end are then the band itself); interleaved rows (rank r owns rows r, r + world, ...): begin = r,
+    // step = world, end - begin = the number of rows owned.  Bins, counters and the raster grid are indexed by k ("owned row"), not by the row itself.
+    uint32_t tile_row_begin, tile_row_end, tile_row_step;
     uint32_t num_draws, total_tris;
     uint32_t total_slots;             // geometry-kernel lanes (every draw padded to a multiple of 64)
     const DrawDesc* draws;
@@ -200,6 +203,7 @@ struct RasterHead {
     uint32_t tiles_x, tile_row_begin, bin_cap, big_cap;
     uint32_t sub_cap, count_stride;   // per-XCD bins (PassParams); read by the two-team variant only
     uint32_t fixed_recs;              // PassParams::fixed_recs
+    uint32_t tile_row_step;           // PassParams::tile_row_step: grid row k is tile row tile_row_begin + k * tile_row_step
 };
 
 // A batched launch: the independent rendering scopes of one mirhi_queue_submit (equal target shape, equal raster variant) share

@@ -52,6 +52,15 @@ __device__ __forceinline__ void store_tri(uint4* dst, const ScreenTri& t) {
                         (uint32_t)t.miny | ((uint32_t)t.maxy << 16));
 }
 
+// Tile-row split: the owned rows (PassParams::tile_row_begin / _step) inside the tile-row range [ty0, ty1], as owned-row indices [k0, k1]; k1 < k0: none.
+__device__ __forceinline__ void owned_rows(ParamsRef P, int32_t ty0, int32_t ty1, int32_t& k0, int32_t& k1) {
+    const int32_t first = (int32_t)P.tile_row_begin, count = (int32_t)P.tile_row_end - first, step = (int32_t)P.tile_row_step;
+    const int32_t a = ty0 - first, b = ty1 - first;
+    if (step <= 1) { k0 = max(a, 0); k1 = min(b, count - 1); return; }          // (wave-uniform: one contiguous band, or no split at all)
+    k0 = a <= 0 ? 0 : (int32_t)(((uint32_t)a + (uint32_t)step - 1u) / (uint32_t)step);
+    k1 = b < 0 ? -1 : min((int32_t)((uint32_t)b / (uint32_t)step), count - 1);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a5: clip-space triangle (all w > 0) -> snapped, culled, oriented screen triangle + depth plane
 // ------------------------------------------------------------------------------------------------
@@ -97,9 +106,12 @@ __device__ __forceinline__ bool setup_triangle(ParamsRef P, DrawRef D, const f4 
     const bool cut = D.scissor_partial && (px0 < D.sx0 || px1 > D.sx1 || py0 < D.sy0 || py1 > D.sy1);
     px0 = max(px0, D.sx0); px1 = min(px1, D.sx1); py0 = max(py0, D.sy0); py1 = min(py1, D.sy1);
     if (px0 > px1 || py0 > py1) return false;
-    // tile rows outside this device's band are not rasterized here (tile-row split)
-    const int32_t band0 = (int32_t)P.tile_row_begin * TILE, band1 = (int32_t)P.tile_row_end * TILE - 1;
-    if (py1 < band0 || py0 > band1) return false;
+    // a triangle that touches none of this device's tile rows is not rasterized here (tile-row split)
+    {
+        int32_t k0, k1;
+        owned_rows(P, py0 >> TILE_LOG2, py1 >> TILE_LOG2, k0, k1);
+        if (k1 < k0) return false;
+    }
     t.minx = px0; t.maxx = px1; t.miny = py0; t.maxy = py1;
     t.boxed = cut ? 1u : 0u;
     t.vminx = xmin; t.vminy = ymin;
@@ -352,17 +364,22 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
     const uint32_t hw_xcd = xcd_of_wave();                           // wave-uniform
     const uint32_t xcd = P.count_stride ? hw_xcd : 0u;               // the list this wave appends to (per-XCD bins)
     const uint32_t fixed_recs = P.fixed_recs;                        // slots below live in the tile's own fixed pages
+    // ty0: the first OWNED row of the triangle's span as an owned-row index (bins and counters are indexed by it); the row itself is
+    // row_first + (ty0 + j) * row_step for the j-th owned row of the span
+    const int32_t row_first = (int32_t)P.tile_row_begin, row_step = max((int32_t)P.tile_row_step, 1);
     int32_t tx0 = 0, ty0 = 0, ntx = 0, nty = 0;
     bool spill = false;
     if (valid) {
-        tx0 = t.minx >> TILE_LOG2; ty0 = max(t.miny >> TILE_LOG2, (int32_t)P.tile_row_begin);
+        int32_t k1;
+        tx0 = t.minx >> TILE_LOG2;
+        owned_rows(P, t.miny >> TILE_LOG2, t.maxy >> TILE_LOG2, ty0, k1);
         ntx = (t.maxx >> TILE_LOG2) - tx0 + 1;
-        nty = min(t.maxy >> TILE_LOG2, (int32_t)P.tile_row_end - 1) - ty0 + 1;
+        nty = k1 - ty0 + 1;
         // a bin record is 16-bit relative to its tile: the triangle's smallest coordinates must be within reach of every tile of
         // its span (they always are unless the triangle hangs far out of the target or the band)
         const int32_t tw = TILE * 256;
         const bool fits = t.compact && t.vminx - tx0 * tw <= 32767 && t.vminx - (tx0 + ntx - 1) * tw >= -32768 &&
-                          t.vminy - ty0 * tw <= 32767 && t.vminy - (ty0 + nty - 1) * tw >= -32768;
+                          t.vminy - (row_first + ty0 * row_step) * tw <= 32767 && t.vminy - (row_first + k1 * row_step) * tw >= -32768;
         spill = ntx > MAX_BIN_SPAN || nty > MAX_BIN_SPAN || !fits;
     }
     const bool binned = valid && !spill;
@@ -374,7 +391,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
     if (__ballot(nb > 1u) == 0ull) {
         // Fine meshes: no triangle of the wave overlaps more than one tile.  A lane is its own pair -- no enumeration
         // through LDS, the record goes out of the registers it was built in.
-        const uint32_t tile = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+        const uint32_t tile = (uint32_t)ty0 * P.tiles_x + (uint32_t)tx0;
         const bool act = nb == 1u;
         uint32_t who;
         const uint32_t raw = reserve_bin_slots(P, act, tile, lane, lt, who, xcd);
@@ -388,7 +405,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         if (in_list && page == PAGE_EMPTY && (slot & (BIN_PAGE_RECS - 1u)) == 0u) page = bin_page_alloc(P, bin_table_entry(P, tile, xcd, slot), hw_xcd);
         if (in_list && page == PAGE_EMPTY) page = bin_page_wait(P, bin_table_entry(P, tile, xcd, slot));
         if (act) {
-            if (in_list && page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, ty0);
+            if (in_list && page != PAGE_NONE) store_bin_rec(P, page, slot, MIRHI_COMPACT_C0, MIRHI_COMPACT_C1, t.idk, tx0, row_first + ty0 * row_step);
             else spill = true;       // list full or pool exhausted: the triangle goes to the big list
         }
         if (valid && spill) emit_big(P, t);
@@ -406,7 +423,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
         lds_tri[lane][0] = MIRHI_COMPACT_C0;
         lds_tri[lane][1] = MIRHI_COMPACT_C1;
         lds_tri[lane][2] = make_uint4(t.idk, (uint32_t)tx0 | ((uint32_t)ty0 << 16), 0u, 0u);
-        lds_meta[lane] = (uint32_t)(ty0 - (int32_t)P.tile_row_begin) * P.tiles_x + (uint32_t)tx0;
+        lds_meta[lane] = (uint32_t)ty0 * P.tiles_x + (uint32_t)tx0;
         uint32_t pos = ex;
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)(MAX_BIN_SPAN * MAX_BIN_SPAN); k++) {
@@ -437,7 +454,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
             }
             slot[k] = reserve_bin_slots(P, act, tile, lane, lt, aux[k], xcd);
         }
-        if (it0 == 0u) overlap();
+        if (it0 == 0u) { GSTAMP(7); overlap(); }
 #pragma unroll
         for (uint32_t k = 0; k < BATCH; k++) {
             if ((it0 + k) * GEOM_THREADS >= total) continue;
@@ -467,7 +484,7 @@ __device__ __forceinline__ void bin_triangle_pairs(ParamsRef P, bool valid, cons
                 if (page != PAGE_NONE) {
                     const uint4 m2 = lds_tri[ol][2];
                     store_bin_rec(P, page, s, lds_tri[ol][0], lds_tri[ol][1], m2.x, (int32_t)(m2.y & 0xFFFFu) + (int32_t)(kk % MAX_BIN_SPAN),
-                                  (int32_t)(m2.y >> 16) + (int32_t)(kk / MAX_BIN_SPAN));
+                                  row_first + ((int32_t)(m2.y >> 16) + (int32_t)(kk / MAX_BIN_SPAN)) * row_step);
                 } else {
                     atomicOr(&lds_meta[ol], 0x80000000u);   // list full / pool exhausted: the owner sends the triangle to the big list, once
                 }
@@ -566,14 +583,21 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
         if (!(o0 & o1 & o2)) {
             any = outcode_clip(c[0], D.gx, D.gy) | outcode_clip(c[1], D.gx, D.gy) | outcode_clip(c[2], D.gx, D.gy);
             bool in_band = true;
-            if (any == 0 && (P.tile_row_begin != 0u || P.tile_row_end != P.tiles_y)) {
-                // tile-row split (one band per GPU): a triangle whose three vertices lie above the band, or below it, is
-                // dropped before the setup arithmetic -- every rank sees all triangles, most belong to other bands.
-                // Clip-space test with a one-pixel margin for the snap: ys = (y/w)*hh + cy, w > 0 here.
-                const float top = D.cy - ((float)(P.tile_row_begin * TILE) - 1.0f), bot = D.cy - ((float)(P.tile_row_end * TILE) + 1.0f);
-                const bool above = c[0].y * D.hh + top * c[0].w < 0.0f && c[1].y * D.hh + top * c[1].w < 0.0f && c[2].y * D.hh + top * c[2].w < 0.0f;
-                const bool below = c[0].y * D.hh + bot * c[0].w > 0.0f && c[1].y * D.hh + bot * c[1].w > 0.0f && c[2].y * D.hh + bot * c[2].w > 0.0f;
-                in_band = !(above || below) || !(c[0].w > 0.0f && c[1].w > 0.0f && c[2].w > 0.0f);
+            if (any == 0 && (P.tile_row_step > 1u || P.tile_row_begin != 0u || P.tile_row_end != P.tiles_y)) {
+                // Tile-row split: every rank sees all triangles and most of them touch none of its rows.  Those are dropped before the setup arithmetic
+                // (the bulk of this kernel's instructions) by a conservative test: the vertices' window y from the 1-ulp reciprocal, a pixel of margin
+                // either way for the snap and for the approximation (|error| < 0.01 px inside the guard band), the tile rows that range spans, and whether
+                // one of them is this rank's (owned_rows).  Whatever passes takes the exact path; what that drops, this may keep -- never the reverse.
+                if (c[0].w > 0.0f && c[1].w > 0.0f && c[2].w > 0.0f) {
+                    const float y0 = c[0].y * __builtin_amdgcn_rcpf(c[0].w), y1 = c[1].y * __builtin_amdgcn_rcpf(c[1].w), y2 = c[2].y * __builtin_amdgcn_rcpf(c[2].w);
+                    const float lo = fminf(y0, fminf(y1, y2)) * D.hh + D.cy - 1.0f, hi = fmaxf(y0, fmaxf(y1, y2)) * D.hh + D.cy + 1.0f;
+                    // (window y grows with clip y when hh > 0; a flipped viewport swaps the two: take the range either way)
+                    const float ylo = fminf(lo + 1.0f, hi - 1.0f) - 1.0f, yhi = fmaxf(lo + 1.0f, hi - 1.0f) + 1.0f;
+                    const int32_t r0 = (int32_t)floorf(fmaxf(ylo, -65536.0f)) >> TILE_LOG2, r1 = (int32_t)floorf(fminf(yhi, 65536.0f)) >> TILE_LOG2;
+                    int32_t k0, k1;
+                    owned_rows(P, r0, r1, k0, k1);
+                    in_band = k1 >= k0;
+                }
             }
             if (any == 0 && in_band) valid = setup_triangle(P, D, c, prim, t);
         }

@@ -109,7 +109,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0) return hipSuccess;
     if (P.ordered_recs) {           // ordered segment: fragments in primitive order (blending)
-        const RasterHead HO = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.bin_cap, 0u, 0u};
+        const RasterHead HO = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.bin_cap, 0u, 0u, P.tile_row_step};
         const dim3 og(P.tiles_x, rows), ob(ORDERED_THREADS);
         if (programs == 2) MIRHI_LAUNCH(ordered_kernel<2>, og, ob, stream, t, dev_params, HO);
         else if (programs == 3) MIRHI_LAUNCH(ordered_kernel<3>, og, ob, stream, t, dev_params, HO);
@@ -120,7 +120,7 @@ hipError_t launch_raster(const PassParams& P, const PassParams* dev_params, uint
     const dim3 grid = P.xcd_swizzle > 1u ? dim3(P.tiles_x * rows) : dim3(P.tiles_x, rows);
     // the plain key (raw float bits) serves LESS / LESS_OR_EQUAL; everything else takes the generic key
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
-    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
+    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs, P.tile_row_step};
     if (P.raster_wide && allow_wide && !P.pred && P.tp_max_area && !P.alpha_scope && (programs == 2 || programs >= 4) && P.xcd_swizzle <= 1u) {
         // the wide mesh variants: eight or sixteen waves per tile (host-side choice, PassParams::raster_wide = waves per tile)
         const bool w16 = P.raster_wide >= 16u;
@@ -198,7 +198,7 @@ hipError_t launch_raster_batch(const PassParams* const* Ps, const PassParams* co
     for (uint32_t i = 0; i < n; i++) {
         const PassParams& Q = *Ps[i];
         B.params[i] = dev_params[i];
-        B.head[i] = RasterHead{Q.bin_count, Q.bin_pool, big_count[i], Q.tiles_x, Q.tile_row_begin, Q.bin_cap, Q.big_cap, Q.sub_cap, Q.count_stride, Q.fixed_recs};
+        B.head[i] = RasterHead{Q.bin_count, Q.bin_pool, big_count[i], Q.tiles_x, Q.tile_row_begin, Q.bin_cap, Q.big_cap, Q.sub_cap, Q.count_stride, Q.fixed_recs, Q.tile_row_step};
     }
     const dim3 grid(P.tiles_x, rows, n);           // (the XCD run-length order of a 1-D grid is a measurement knob: such scopes are not batched)
     const bool plain = P.zflip == 0u && P.zmask == 0xFFFFFFFFu;
@@ -215,7 +215,7 @@ bool raster_batchable(const PassParams& P) { return !P.pred && P.zflip == 0u && 
 hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_params, uint32_t* big_count, hipStream_t stream, LaunchTiming t) {
     const uint32_t rows = P.tile_row_end - P.tile_row_begin;
     if (rows == 0 || P.tiles_x == 0 || P.ordered_recs) return hipSuccess;
-    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs};
+    const RasterHead H = {P.bin_count, P.bin_pool, big_count, P.tiles_x, P.tile_row_begin, P.bin_cap, P.big_cap, P.sub_cap, P.count_stride, P.fixed_recs, P.tile_row_step};
     MIRHI_LAUNCH(fragment_count_kernel, dim3(P.tiles_x, rows), dim3(RASTER_THREADS), stream, t, dev_params, H);
     return launch_result();
 }

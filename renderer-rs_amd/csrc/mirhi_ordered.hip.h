@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ORDERED_THREADS, 2) void ordered_kernel(const PassP
     __shared__ uint32_t lds_state[6 * 4 * ORDERED_THREADS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t tx = blockIdx.x, tyr = blockIdx.y, ty = H.tile_row_begin + tyr, tile = tyr * H.tiles_x + tx;
+    const uint32_t tx = blockIdx.x, tyr = blockIdx.y, ty = H.tile_row_begin + tyr * H.tile_row_step, tile = tyr * H.tiles_x + tx;
     const int32_t ix0 = (int32_t)((q & 1u) * 16u + (lane & 7u)), iy0 = (int32_t)((q >> 1) * 16u + (lane >> 3));
     const float fix0 = (float)ix0, fiy0 = (float)iy0;
     const uint32_t qbit0 = 1u << ((q >> 1) * 8u + (q & 1u) * 2u), qmask = qbit0 * 0x33u;

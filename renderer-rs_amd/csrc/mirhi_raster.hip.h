@@ -655,7 +655,7 @@ __device__ __forceinline__ void raster_body(const PassParams* __restrict__ param
         }
         tx = t % H.tiles_x; tyr = t / H.tiles_x;
     }
-    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
+    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr * H.tile_row_step;      // (grid row = owned row: PassParams::tile_row_step)
     // four waves: wave q owns the 16x16 quadrant q (blocks b: bx = b & 1, by = b >> 1 from its first); eight: the 16x8 strip
     // (q & 1, q >> 1), two blocks side by side; sixteen: block q (bx = q & 3, by = q >> 2)
     const int32_t ix0 = WPT == 16 ? (int32_t)((q & 3u) * 8u + (lane & 7u)) : (int32_t)((q & 1u) * 16u + (lane & 7u));

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void fragment_count_kernel(const Pa
     ParamsRef P = *(ParamsPtr)(uintptr_t)params;
     __shared__ uint32_t lds_sum;
     const uint32_t tx = blockIdx.x, tyr = blockIdx.y, tid = threadIdx.x;
-    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr;
+    const uint32_t tile = tyr * H.tiles_x + tx, ty = H.tile_row_begin + tyr * H.tile_row_step;
     if (tid == 0) lds_sum = 0;
     __syncthreads();
     uint32_t n = 0;

@@ -29,6 +29,27 @@ def band_rows(height: int, rank: int, world: int):
     return min(b * TILE, height), min(e * TILE, height)
 
 
+def split_tile_rows(height: int, rank: int, world: int, layout: str = "interleaved"):
+    """The tile rows `rank` of `world` rasterizes, as split_rows() in csrc/mirhi_api.hip gives them: (first, step, count)."""
+    ty = tiles_y(height)
+    if world <= 1:
+        return 0, 1, ty
+    if layout == "bands":
+        b, e = band_tile_rows(height, rank, world)
+        return b, 1, e - b
+    return rank, world, ((ty - rank + world - 1) // world if rank < ty else 0)
+
+
+def owned_pixel_rows(height: int, rank: int, world: int, layout: str = "interleaved"):
+    """[(begin, end)] pixel-row runs of the frame that `rank` renders (one run per band / per owned tile row), as mirhi_comm_all_gather_bands sends them"""
+    first, step, count = split_tile_rows(height, rank, world, layout)
+    if step == 1:
+        runs = [(first * TILE, (first + count) * TILE)]
+    else:
+        runs = [((first + k * step) * TILE, (first + k * step + 1) * TILE) for k in range(count)]
+    return [(min(b, height), min(e, height)) for b, e in runs if min(b, height) < min(e, height)]
+
+
 def rows_per_rank(height: int, world: int) -> int:
     return ((tiles_y(height) + world - 1) // world) * TILE
 
@@ -60,20 +81,20 @@ def all_gather_bands(frame, rank: int, world: int, group=None, via_host: bool = 
     return frame
 
 
-def exchange_bands_direct(frame, height: int, rank: int, world: int, group=None):
+def exchange_bands_direct(frame, height: int, rank: int, world: int, group=None, layout: str = "bands"):
     """The MIRHI_GATHER_DIRECT pattern of mirhi_comm_all_gather_bands (csrc/mirhi_api.hip) on torch.distributed: every rank
-    sends its band straight to every peer and receives theirs, one batch of point-to-point transfers, in place on an UNPADDED
-    (height, W, C) frame -- bands may differ in size (the last one is short when the tile rows do not divide)."""
+    sends the rows it rendered straight to every peer and receives theirs, one batch of point-to-point transfers, in place on an UNPADDED
+    (height, W, C) frame -- shares may differ in size (the last band / tile row is short when the rows do not divide); with interleaved rows
+    a rank's share is one piece per tile row it owns."""
     import torch.distributed as dist
-    b0, e0 = band_rows(height, rank, world)
+    mine = owned_pixel_rows(height, rank, world, layout)
     ops = []
     for r in range(world):
         if r == rank:
             continue
-        b, e = band_rows(height, r, world)
-        if e0 > b0:
+        for b0, e0 in mine:
             ops.append(dist.P2POp(dist.isend, frame[b0:e0], r, group=group))
-        if e > b:
+        for b, e in owned_pixel_rows(height, r, world, layout):
             ops.append(dist.P2POp(dist.irecv, frame[b:e], r, group=group))
     if ops:
         for req in dist.batch_isend_irecv(ops):

@@ -25,7 +25,8 @@ CASES = [  # width, height, ranks, algorithm
     (256, 96, 5, "DIRECT"),                                                                                     # 3 tile rows for 5 ranks: two ranks own nothing
 ]
 failures = 0
-for (W, H, N, algo_name) in CASES:
+# every case with one contiguous band per rank and with interleaved tile rows (rank r: rows r, r + N, ...: one piece per owned row in the exchange)
+for (W, H, N, algo_name, layout) in [c + (lay,) for lay in ("bands", "interleaved") for c in CASES]:
     scene = m.scenes.random_triangles(500, W, H, seed=1000 + N, rmin=3, rmax=40)
     solo = m.Device(0)
     res0 = m.SceneResources(solo, scene, m.Format.B8G8R8A8_SRGB)
@@ -33,9 +34,13 @@ for (W, H, N, algo_name) in CASES:
     ref = res0.read()["color"].copy()
     res0.destroy(); solo.destroy()
     devs = [m.Device(0) for _ in range(N)]
+    for d in devs:
+        d.set_split_layout(layout)
     uid = m.Comm.unique_id()
     comms = [m.Comm(devs[r], uid, r, N) for r in range(N)]          # (sets the device's tile split: the frames are recorded behind it)
     assert all(c.world() == N for c in comms)
+    from renderer_rs_amd import multigpu
+    assert all(devs[r].split_rows(H) == multigpu.split_tile_rows(H, r, N, layout) for r in range(N))
     ress = [m.SceneResources(devs[r], scene, m.Format.B8G8R8A8_SRGB) for r in range(N)]
     algo = getattr(m.GatherAlgo, algo_name)
     moved0 = mock.mock_rccl_bytes()
@@ -55,16 +60,16 @@ for (W, H, N, algo_name) in CASES:
         got = ress[r].read()["color"]
         if not np.array_equal(got, ref):
             bad = np.argwhere((got != ref).any(axis=2))
-            print(f"MISMATCH {W}x{H} N={N} {algo_name}: rank {r} differs in {len(bad)} pixels, first at row {bad[0][0]}")
+            print(f"MISMATCH {W}x{H} N={N} {algo_name} {layout}: rank {r} differs in {len(bad)} pixels, first at row {bad[0][0]}")
             ok = False
     want = 2 * (N - 1) * W * H * 4
     if moved != want:
-        print(f"BYTES {W}x{H} N={N} {algo_name}: moved {moved}, expected {want}")
+        print(f"BYTES {W}x{H} N={N} {algo_name} {layout}: moved {moved}, expected {want}")
         ok = False
     failures += 0 if ok else 1
     for r in range(N):
         ress[r].destroy(); devs[r].destroy()
-    print(f"{W}x{H} ranks {N} {algo_name}: {'ok' if ok else 'FAILED'} ({moved} bytes exchanged)", flush=True)
+    print(f"{W}x{H} ranks {N} {algo_name} {layout}: {'ok' if ok else 'FAILED'} ({moved} bytes exchanged)", flush=True)
 # A failing ncclSend inside the grouped exchange (ADVICE r2 / VERDICT r2 item 6b): the call reports it, the thread's RCCL group is closed
 # again (an open group would swallow every later RCCL call of the thread), and the next exchange works.
 mock.mock_rccl_group_depth.restype = ctypes.c_int

@@ -191,28 +191,40 @@ def test_device_refuses_destroy_with_live_children(mirhi):
     dev.destroy()
 
 
-def test_tile_row_split_bands_assemble(mirhi, oracle, scenes):
-    """each rank renders its band of tile rows; bands tile the frame exactly."""
+@pytest.mark.parametrize("layout", ["bands", "interleaved"])
+def test_tile_row_split_rows_assemble(mirhi, oracle, scenes, layout):
+    """each rank renders the tile rows it owns -- one contiguous band, or rows rank, rank + world, ... (interleaved) -- and the
+    ranks' rows tile the frame exactly; nothing outside a rank's rows is touched."""
     from renderer_rs_amd import multigpu
     scene = scenes.random_triangles(3000, 640, 360, seed=12, rmin=3, rmax=60)
     ref = oracle.render(scene, want_bgra8=False)
     world = 4
     out_prim = np.full((scene.height, scene.width), 0xFFFFFFFF, dtype=np.uint32)
     out_col = np.zeros((scene.height, scene.width, 4), dtype=np.float32)
+    covered = np.zeros(scene.height, dtype=np.int32)
     for rank in range(world):
         dev = mirhi.Device(0)
-        dev.set_tile_split(rank, world)
-        r0, r1 = dev.band_rows(scene.height)
-        assert (r0, r1) == multigpu.band_rows(scene.height, rank, world)
+        dev.set_tile_split(rank, world, layout=layout)
+        assert dev.split_rows(scene.height) == multigpu.split_tile_rows(scene.height, rank, world, layout)
+        if layout == "bands":
+            assert dev.band_rows(scene.height) == multigpu.band_rows(scene.height, rank, world)
+        else:
+            with pytest.raises(mirhi.RhiError):
+                dev.band_rows(scene.height)                       # (no single band: split_rows is the query)
         res = mirhi.SceneResources(dev, scene, want_prim=True)
         res.color.upload(np.full((scene.height, scene.width, 4), -7.0, dtype=np.float32))   # sentinel
         res.render()
         got = res.read()
-        assert (got["color"][:r0] == -7.0).all() and (got["color"][r1:] == -7.0).all()       # other bands untouched
-        out_prim[r0:r1] = got["prim"][r0:r1]
-        out_col[r0:r1] = got["color"][r0:r1]
+        mine = np.zeros(scene.height, dtype=bool)
+        for r0, r1 in multigpu.owned_pixel_rows(scene.height, rank, world, layout):
+            mine[r0:r1] = True
+        assert (got["color"][~mine] == -7.0).all()                # the other ranks' rows untouched
+        out_prim[mine] = got["prim"][mine]
+        out_col[mine] = got["color"][mine]
+        covered += mine
         res.destroy()
         dev.destroy()
+    assert (covered == 1).all()
     assert np.array_equal(out_prim, ref["prim"])
     assert np.abs(out_col[..., :3] - ref["rgba"][..., :3]).max() < 1e-4
 
@@ -916,4 +928,4 @@ def test_band_exchange_with_n_ranks_on_one_gpu(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "mock", "split_exchange_check.py"), lib], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
-    assert p.stdout.count(": ok") == 8, p.stdout[-3000:]       # 7 exchanges + the failing-send case (the group is closed again, the next exchange works)
+    assert p.stdout.count(": ok") == 15, p.stdout[-3000:]      # 7 exchanges x 2 layouts (bands, interleaved rows) + the failing-send case (the group is closed again, the next exchange works)

@@ -428,12 +428,13 @@ def test_batched_submit_matches_oracle(mirhi, oracle, scenes, program):
     dev.destroy()
 
 
+@pytest.mark.parametrize("layout", ["bands", "interleaved"])
 @pytest.mark.parametrize("config", ["c4", "c5"])
-def test_full_size_eight_way_tile_row_split_equals_the_unsplit_frame(mirhi, scenes, config):
-    """BASELINE configs[3] and [4] as they are defined: 3840x2160 split by tile rows across 8 ranks (68 tile rows: seven bands of 9, the
-    last of 5 -- 288 pixel rows each, 160 in the last).  Each rank's band, rendered here one after the other into one sRGB8 target through
-    the bench path (no primitive-id image), must tile the frame exactly: byte for byte the unsplit render (which the full-size tests
-    above compare with the oracle).  Rows outside a rank's band stay untouched."""
+def test_full_size_eight_way_tile_row_split_equals_the_unsplit_frame(mirhi, scenes, config, layout):
+    """BASELINE configs[3] and [4] as they are defined: 3840x2160 split by tile rows across 8 ranks -- 68 tile rows: seven bands of 9 and one
+    of 5 (288 pixel rows each, 160 in the last), or interleaved rows r, r + 8, ... (9 tile rows for ranks 0-3, 8 for ranks 4-7).  Each rank's
+    rows, rendered here one after the other into one sRGB8 target through the bench path (no primitive-id image), must tile the frame exactly:
+    byte for byte the unsplit render (which the full-size tests above compare with the oracle).  Rows of other ranks stay untouched."""
     from renderer_rs_amd import multigpu
     scene = scenes.heightfield_grid() if config == "c4" else scenes.box_hall()
     dev = mirhi.Device(0)
@@ -443,18 +444,18 @@ def test_full_size_eight_way_tile_row_split_equals_the_unsplit_frame(mirhi, scen
     whole.destroy()
     world = 8
     assert [multigpu.band_rows(scene.height, r, world) for r in (0, 6, 7)] == [(0, 288), (1728, 2016), (2016, 2160)]
+    assert [multigpu.split_tile_rows(scene.height, r, world, "interleaved") for r in (0, 3, 4, 7)] == [(0, 8, 9), (3, 8, 9), (4, 8, 8), (7, 8, 8)]
     target = mirhi.Image(dev, scene.width, scene.height, mirhi.Format.B8G8R8A8_SRGB)
-    sentinel = np.full((scene.height, scene.width, 4), 0xA5, dtype=np.uint8)
-    target.upload(sentinel)
+    expect = np.full((scene.height, scene.width, 4), 0xA5, dtype=np.uint8)
+    target.upload(expect)
     for rank in range(world):
-        dev.set_tile_split(rank, world)
-        r0, r1 = dev.band_rows(scene.height)
+        dev.set_tile_split(rank, world, layout=layout)
         res = mirhi.SceneResources(dev, scene, mirhi.Format.B8G8R8A8_SRGB, color_image=target)
         res.render()
         dev.wait_idle()
-        got = target.read()
-        assert np.array_equal(got[r0:r1], ref[r0:r1]), f"{config}: band {rank} differs from the unsplit frame"
-        assert (got[r1:] == 0xA5).all(), f"{config}: band {rank} wrote below its rows"
+        for r0, r1 in multigpu.owned_pixel_rows(scene.height, rank, world, layout):
+            expect[r0:r1] = ref[r0:r1]
+        assert np.array_equal(target.read(), expect), f"{config} {layout}: rank {rank}'s rows differ from the unsplit frame, or it wrote outside them"
         res.color = None
         res.destroy()
     assert np.array_equal(target.read(), ref)

@@ -53,6 +53,27 @@ def test_band_rows_partition(mirhi):
             assert multigpu.padded_rows(height, world) >= height and multigpu.padded_rows(height, world) % world == 0
 
 
+def test_split_tile_rows_partition_both_layouts(mirhi):
+    """every tile row of a frame belongs to exactly one rank, with one band per rank and with interleaved rows; the pixel-row runs a rank sends
+    (multigpu.owned_pixel_rows = the pieces of mirhi_comm_all_gather_bands) cover the frame exactly once"""
+    from renderer_rs_amd import multigpu
+    for layout in ("bands", "interleaved"):
+        for height in (1080, 2160, 64, 33, 97):
+            for world in (1, 2, 3, 4, 8):
+                owner = np.full(multigpu.tiles_y(height), -1)
+                rows = np.zeros(height, dtype=np.int32)
+                for r in range(world):
+                    first, step, count = multigpu.split_tile_rows(height, r, world, layout)
+                    for k in range(count):
+                        assert owner[first + k * step] == -1
+                        owner[first + k * step] = r
+                    for b, e in multigpu.owned_pixel_rows(height, r, world, layout):
+                        rows[b:e] += 1
+                assert (owner >= 0).all() and (rows == 1).all()
+    assert multigpu.split_tile_rows(2160, 3, 8, "interleaved") == (3, 8, 9) and multigpu.split_tile_rows(2160, 4, 8, "interleaved") == (4, 8, 8)
+    assert multigpu.owned_pixel_rows(1080, 1, 4, "interleaved")[-1] == (33 * 32, 1080)      # the frame's last tile row is 24 pixel rows
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -87,6 +108,12 @@ def _split_worker(rank, world, port, out_dir, width=200, height=150):
     direct[r0:r1] = torch.from_numpy(band[r0:r1])
     multigpu.exchange_bands_direct(direct, scene.height, rank, world)
     ok = ok and bool((direct.numpy() == full).all())
+    # ... and with interleaved tile rows: a rank's share is one piece per tile row it owns
+    inter = torch.zeros((scene.height, scene.width, 4), dtype=torch.uint8)
+    for b, e in multigpu.owned_pixel_rows(scene.height, rank, world, "interleaved"):
+        inter[b:e] = torch.from_numpy(ob.render(scene, rows=(b, e))["bgra8"][b:e])
+    multigpu.exchange_bands_direct(inter, scene.height, rank, world, layout="interleaved")
+    ok = ok and bool((inter.numpy() == full).all())
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()

@@ -17,21 +17,22 @@ for i in range(n):
     rng = np.random.default_rng(seed)
     scene = (fz._random_scene if i % 2 == 0 else fz._random_pbr_scene)(m.scenes, seed)
     world = int(rng.integers(2, 9))
+    layout = "bands" if (i // 2) % 2 == 0 else "interleaved"
     ref = ob.render(scene, want_bgra8=False)
     prim = np.full((scene.height, scene.width), 0xFFFFFFFF, dtype=np.uint32)
     color = np.zeros((scene.height, scene.width, 4), dtype=np.float32)
     for rank in range(world):
         dev = m.Device(0)
-        dev.set_tile_split(rank, world)
+        dev.set_tile_split(rank, world, layout=layout)
         res = m.SceneResources(dev, scene, want_prim=True)
         res.render(); out = res.read(); res.destroy(); dev.destroy()
-        r0, r1 = multigpu.band_rows(scene.height, rank, world)
-        prim[r0:r1] = out["prim"][r0:r1]; color[r0:r1] = out["color"][r0:r1]
+        for r0, r1 in multigpu.owned_pixel_rows(scene.height, rank, world, layout):
+            prim[r0:r1] = out["prim"][r0:r1]; color[r0:r1] = out["color"][r0:r1]
     ok = np.array_equal(prim, ref["prim"])
     nan = np.isnan(ref["rgba"])
     err = float((np.abs(np.where(nan, 0, color) - np.where(nan, 0, ref["rgba"])) / np.maximum(1.0, np.abs(np.where(nan, 0, ref["rgba"])))).max())
     if not ok or err >= 1e-4:
         bad += 1
-        print(f"MISMATCH seed={seed} world={world} prim_ok={ok} err={err}", flush=True)
+        print(f"MISMATCH seed={seed} world={world} layout={layout} prim_ok={ok} err={err}", flush=True)
 print(f"done: {n} scenes, {bad} mismatches")
 sys.exit(1 if bad else 0)

@@ -2,7 +2,7 @@
 dispatches, event pair on each), and the 1 -> N curve is PREDICTED from them: a frame's time on N GPUs = the slowest rank's kernels, or the
 band exchange if that is longer (direct sends over a full xGMI mesh: every link carries one band, frame_bytes / N at 153 GB/s; the exchange
 of frame f overlaps the kernels of frame f + 1 with two frames in flight).  Nothing here has run on more than one GPU.
-usage: split_times.py [--json out.json] [workloads...]      (default: c4 c5)"""
+usage: split_times.py [--json out.json] [--layout bands|interleaved|both] [workloads...]      (default: both layouts, c4 c5)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
@@ -11,6 +11,9 @@ args = sys.argv[1:]
 out_path = None
 if "--json" in args:
     i = args.index("--json"); out_path = args[i + 1]; del args[i:i + 2]
+layouts = ["bands", "interleaved"]
+if "--layout" in args:
+    i = args.index("--layout"); layouts = layouts if args[i + 1] == "both" else [args[i + 1]]; del args[i:i + 2]
 LINK_GBS = 153.0
 result = {"note": "emulated on one MI355X: per-rank kernel times are measured (isolated dispatches), the curve is predicted from them", "link_GB_per_s": LINK_GBS, "workloads": {}}
 for wl in args or ["c4", "c5"]:
@@ -18,10 +21,10 @@ for wl in args or ["c4", "c5"]:
     frame_bytes = scene.width * scene.height * 4
     table = {}
 
-    def measure(rank, world):
+    def measure(rank, world, layout="bands"):
         dev = m.Device(0)
         if world > 1:
-            dev.set_tile_split(rank, world)
+            dev.set_tile_split(rank, world, layout=layout)
         res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
         for _ in range(6):
             res.render()
@@ -37,15 +40,15 @@ for wl in args or ["c4", "c5"]:
     t1 = sum(one.values())
     table["1"] = {"ranks": [one], "frame_us": round(t1, 2), "speedup": 1.0}
     print(f"{wl} world 1: {one} = {t1:.1f} us", flush=True)
-    for world in (2, 4, 8):
-        ranks = [measure(r, world) for r in range(world)]
+    for layout, world in [(lay, w) for lay in layouts for w in (2, 4, 8)]:
+        ranks = [measure(r, world, layout) for r in range(world)]
         slow = max(sum(r.values()) for r in ranks)
         exch = 1e6 * (frame_bytes / world) / (LINK_GBS * 1e9)
         frame = max(slow, exch)
         fixed = min(r["geometry"] for r in ranks) / one["geometry"] if one["geometry"] else 0.0
-        table[str(world)] = {"ranks": ranks, "slowest_rank_kernels_us": round(slow, 2), "exchange_us_modelled": round(exch, 2), "frame_us_predicted": round(frame, 2),
+        table[f"{world} {layout}"] = {"layout": layout, "ranks": ranks, "slowest_rank_kernels_us": round(slow, 2), "exchange_us_modelled": round(exch, 2), "frame_us_predicted": round(frame, 2),
                              "speedup_predicted": round(t1 / frame, 2), "geometry_share_of_cheapest_rank": round(fixed, 3)}
-        print(f"{wl} world {world}: slowest rank {slow:.1f} us (vertex / geometry / raster per rank: " +
+        print(f"{wl} world {world} {layout}: slowest rank {slow:.1f} us (vertex / geometry / raster per rank: " +
               " | ".join(f"{r['vertex']:.1f}/{r['geometry']:.1f}/{r['raster']:.1f}" for r in ranks) + f"), exchange {exch:.1f} us -> predicted x{t1 / frame:.2f}", flush=True)
     result["workloads"][wl] = {"triangles": scene.num_triangles, "width": scene.width, "height": scene.height, "worlds": table}
 if out_path:

@@ -46,7 +46,7 @@ nb = min(16384, (scene.num_triangles + tpw - 1) // tpw)
 g = g[:nb]; g = g[g[:, 3] > 0]
 print(f"geometry waves sampled {len(g)} ({tpw} triangles per wave): kernel span {us(g[:,3].max() - g[:,0].min()):.2f} us (first start -> last end), wave start spread p50 {us(np.median(g[:,0] - g[:,0].min())):.2f} max {us((g[:,0] - g[:,0].min()).max()):.2f} us")
 for name, a, b in (("  entry -> draw descriptor in registers", 0, 4), ("  -> indices + vertices in registers", 4, 5), ("  -> setup done", 5, 6), ("  -> flat colour stored", 6, 1),
-                   ("fetch + vs + setup", 0, 1), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
+                   ("fetch + vs + setup", 0, 1), ("  pairs enumerated, reservations issued", 1, 7), ("  -> records stored (issued)", 7, 2), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
     d = g[:, b] - g[:, a]
     print(f"  {name:36s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
 res.destroy(); dev.destroy()
