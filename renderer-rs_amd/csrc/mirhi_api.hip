@@ -437,6 +437,7 @@ struct mirhi_device {
     // native dispatch (mirhi_native.h): one AQL queue per queue lane, opened when the lane first carries a native submit
     NativeDevice* native = nullptr;
     std::vector<NativeQueue*> native_lanes;
+    std::vector<hipStream_t> aux_streams;     // streams of the device's communicators (band exchange): wait_idle waits for them, an image they wrote last is ordered behind them
     bool native_on_external = false;          // mirhi_device_set_native_dispatch: lane 0 of a device made on the caller's stream dispatches natively too
     mirhi_result deferred = MIRHI_OK;         // status of such a command buffer that no fence listed: reported by wait_idle
     std::string deferred_msg;
@@ -725,6 +726,7 @@ static mirhi_result sync_all_lanes(mirhi_device* dev) {
     bool ok = true;
     for (NativeQueue* nq : dev->native_lanes) ok = native_queue_drain(nq) && ok;
     for (hipStream_t st : dev->lanes) HIP_TRY(hipStreamSynchronize(st));
+    for (hipStream_t st : dev->aux_streams) HIP_TRY(hipStreamSynchronize(st));
     return ok ? MIRHI_OK : device_lost(dev);
 }
 // the AQL queue of a queue lane (opened on first use; native_lanes is sized with the lanes -- mirhi_device_set_queue_lanes -- so that threads that walk it
@@ -2241,6 +2243,7 @@ static mirhi_result order_attachments(mirhi_device* dev, mirhi_cmd* c, hipStream
             else {
                 bool live = false;
                 for (hipStream_t st : dev->lanes) live |= st == img->last_stream;
+                for (hipStream_t st : dev->aux_streams) live |= st == img->last_stream;       // (a band exchange wrote the image last)
                 if (live && nq) err = hipStreamSynchronize(img->last_stream);
                 else if (live) {
                     if (!dev->order_event) err = hipEventCreateWithFlags(&dev->order_event, hipEventDisableTiming);
@@ -2375,7 +2378,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
     // (its clear is a HIP memset), every command buffer on one lane.
     // A device made on the caller's stream (mirhi_device_create_on_stream) promised that lane 0's work is issued on that stream: submits to lane 0 stay in
     // stream order (HIP launches) unless the caller opted in (mirhi_device_set_native_dispatch); lanes the library made itself are the library's.
-    bool use_native = !batched && cmd_count >= 1 && dev->native && dev->native->ok && dev->profiling == 0 && dev->split_world == 1 &&
+    bool use_native = !batched && cmd_count >= 1 && dev->native && dev->native->ok && dev->profiling == 0 &&
                       (dev->owns_stream || dev->native_on_external || cmds[0]->lane != 0u);
     for (uint32_t i = 0; use_native && i < cmd_count; i++) {
         use_native = cmds[i]->lane == cmds[0]->lane && cmds[i]->lane < dev->lanes.size();
@@ -2940,6 +2943,15 @@ struct mirhi_comm {
     // totally ordered stream, and frames in flight on other lanes keep rendering while a band exchange is under way.
     hipStream_t stream;
     hipEvent_t ready, done;       // lane -> exchange stream, exchange stream -> lane
+    // Interleaved tile rows: a rank's share of the frame is one 32-row piece per tile row it owns, a tile row of the frame apart.  Sending the pieces one by
+    // one would put (world - 1) x 2 x ~9 point-to-point operations into the group for a 4K frame on 8 ranks; instead the share is packed into slot `rank` of
+    // this buffer (one strided device-to-device copy), ONE message per peer goes out of it and ONE comes into every other slot -- the op count of the
+    // band layout -- and the received slots are scattered into the frame (one strided copy per peer).  [world][slot_bytes], grown on demand.
+    uint8_t* pack = nullptr; size_t pack_bytes = 0;
+    // A frame that left the library as AQL packets (native dispatch) is followed on its queue by one single-lane kernel that stores the exchange's sequence
+    // number into `seq_word` (signal memory), and the exchange stream waits for that value (hipStreamWaitValue64): the stream is ordered behind the
+    // frame's raster kernel without the host waiting for anything.
+    uint64_t* seq_word = nullptr; uint64_t seq = 0;
 };
 #define RCCL_TRY(R, expr)                                                                                     \
     do {                                                                                                      \
@@ -2979,6 +2991,9 @@ extern "C" mirhi_result mirhi_comm_create(mirhi_device* dev, const uint8_t* id, 
         (void)hipGetLastError(); (void)R->CommDestroy(comm); delete c;
         return fail(MIRHI_ERR_DEVICE, "Vulkan error: stream / event creation for the band exchange failed");
     }
+    // signal memory for ordering the exchange stream behind natively dispatched frames (without it the host waits for the frame instead)
+    { void* w = nullptr; if (hipExtMallocWithFlags(&w, 8, hipMallocSignalMemory) == hipSuccess) { c->seq_word = (uint64_t*)w; *c->seq_word = 0; } else (void)hipGetLastError(); }
+    { std::lock_guard<std::mutex> lk(dev->mu); dev->aux_streams.push_back(c->stream); }
     dev->split_rank = rank; dev->split_world = world;
     dev->children++;
     *out = c;
@@ -2996,55 +3011,88 @@ extern "C" mirhi_result mirhi_comm_all_gather_bands(mirhi_comm* comm, mirhi_imag
         return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: the device's tile split (%u of %u) is not the communicator's (%u of %u)", dev->split_rank, dev->split_world, comm->rank, comm->world);
     drain_submits(dev);
     HIP_TRY(hipSetDevice(dev->ordinal));
-    if (after && after->last_native && !drain_native(dev, after->last_native)) return device_lost(dev);     // (frames of a split go through HIP; one rendered before the split was set may not have)
     hipStream_t lane = after && after->last_stream ? after->last_stream : dev->lanes[after && after->lane < dev->lanes.size() ? after->lane : 0];
+    NativeQueue* const native_after = (after && after->last_native && comm->seq_word) ? after->last_native : nullptr;
+    if (after && after->last_native && !native_after && !drain_native(dev, after->last_native)) return device_lost(dev);     // (no signal memory: the host waits for the frame)
     hipStream_t stream = comm->stream;
-    dev->foreign_writes++;                                   // (peers write the other bands into this frame)
+    dev->foreign_writes++;                                   // (peers write the other ranks' rows into this frame)
     const uint32_t tiles_y = (frame->height + TILE - 1) / TILE;
     const size_t row_bytes = (size_t)frame->width * format_bpp(frame->format);
+    const size_t tile_row_bytes = (size_t)TILE * row_bytes;
     Rccl* R = comm->rccl;
-    // the pieces of the frame rank r rendered: one run of pixel rows per tile row it owns (bands: the rows are adjacent and go as ONE piece; interleaved:
-    // rank r's tile rows r, r + world, ... are 32 pixel rows each, a tile row of the frame apart -- every piece is contiguous in the row-major image)
-    struct Piece { size_t off, bytes; };
-    auto pieces = [&](uint32_t r, std::vector<Piece>& out) {
-        out.clear();
-        uint32_t first, step, count;
-        split_rows(dev->split_layout, r, comm->world, tiles_y, &first, &step, &count);
-        auto run = [&](uint32_t t0, uint32_t t1) {
-            size_t p0 = (size_t)t0 * TILE, p1 = (size_t)t1 * TILE;
-            if (p0 > frame->height) p0 = frame->height;
-            if (p1 > frame->height) p1 = frame->height;
-            if (p1 > p0) out.push_back(Piece{p0 * row_bytes, (p1 - p0) * row_bytes});
-        };
-        if (step == 1) run(first, first + count);
-        else for (uint32_t k = 0; k < count; k++) run(first + k * step, first + k * step + 1);
+    // rank r's share: tile rows first + k * step, k < count; the frame's last tile row may be short
+    struct Share { uint32_t first, step, count; size_t bytes; };
+    auto share = [&](uint32_t r) {
+        Share sh{0, 1, 0, 0};
+        split_rows(dev->split_layout, r, comm->world, tiles_y, &sh.first, &sh.step, &sh.count);
+        for (uint32_t k = 0; k < sh.count; k++) {
+            const size_t p0 = (size_t)(sh.first + k * sh.step) * TILE, p1 = std::min<size_t>(p0 + TILE, frame->height);
+            sh.bytes += (p1 > p0 ? p1 - p0 : 0) * row_bytes;
+        }
+        return sh;
     };
-    std::vector<Piece> mine, theirs;
-    pieces(comm->rank, mine);
+    const Share mine = share(comm->rank);
     if (comm->world == 1) return MIRHI_OK;
-    HIP_TRY(hipEventRecord(comm->ready, lane));              // the exchange starts behind the frame's raster kernel ...
-    HIP_TRY(hipStreamWaitEvent(stream, comm->ready, 0));
+    const bool packed = dev->split_layout == MIRHI_SPLIT_INTERLEAVED;
+    const size_t slot_bytes = ((tiles_y + comm->world - 1) / comm->world) * tile_row_bytes;
+    if (packed && comm->pack_bytes < slot_bytes * comm->world) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (comm->pack) { (void)hipFree(comm->pack); comm->pack = nullptr; comm->pack_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&comm->pack, slot_bytes * comm->world));
+        comm->pack_bytes = slot_bytes * comm->world;
+    }
+    // strided copy between a rank's rows in the frame and its slot of the pack buffer (to_slot: gather, else scatter); the last tile row of the frame may be short
+    auto strided = [&](const Share& sh, uint8_t* slot, bool to_slot) -> hipError_t {
+        if (!sh.count) return hipSuccess;
+        uint8_t* rows = frame->ptr + (size_t)sh.first * tile_row_bytes;
+        const size_t pitch = (size_t)sh.step * tile_row_bytes;
+        const size_t last_p0 = (size_t)(sh.first + (sh.count - 1) * sh.step) * TILE;
+        const size_t last_bytes = (std::min<size_t>(last_p0 + TILE, frame->height) - last_p0) * row_bytes;
+        const uint32_t full = last_bytes == tile_row_bytes ? sh.count : sh.count - 1;
+        hipError_t e = hipSuccess;
+        if (full) e = to_slot ? hipMemcpy2DAsync(slot, tile_row_bytes, rows, pitch, tile_row_bytes, full, hipMemcpyDeviceToDevice, stream)
+                              : hipMemcpy2DAsync(rows, pitch, slot, tile_row_bytes, tile_row_bytes, full, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess && full < sh.count && last_bytes)
+            e = to_slot ? hipMemcpyAsync(slot + (size_t)full * tile_row_bytes, rows + (size_t)full * pitch, last_bytes, hipMemcpyDeviceToDevice, stream)
+                        : hipMemcpyAsync(rows + (size_t)full * pitch, slot + (size_t)full * tile_row_bytes, last_bytes, hipMemcpyDeviceToDevice, stream);
+        return e;
+    };
+    // the exchange starts behind the frame's raster kernel ...
+    if (native_after) {
+        const uint64_t want = ++comm->seq;
+        { const hipError_t ne = launch_seq_store(native_after, comm->seq_word, want); if (ne != hipSuccess) return dev->native->lost.load() ? device_lost(dev) : hip_fail(ne, "sequence store behind the frame"); }
+        HIP_TRY(hipStreamWaitValue64(stream, comm->seq_word, want, hipStreamWaitValueGte, ~0ull));
+    } else {
+        HIP_TRY(hipEventRecord(comm->ready, lane));
+        HIP_TRY(hipStreamWaitEvent(stream, comm->ready, 0));
+    }
+    if (packed) HIP_TRY(strided(mine, comm->pack + comm->rank * slot_bytes, true));
     RCCL_TRY(R, R->GroupStart());
     // Inside the group nothing returns early: a failing call must not leave the thread's RCCL group open (every later RCCL call of
     // this thread, torch.distributed's included, would queue into a group that never ends).  The first error is kept, the group is
-    // closed, and only a successful exchange makes the lane wait for it.  All pieces of all peers travel in this ONE group: RCCL fuses the
-    // point-to-point transfers of a group into one launch per peer pair (interleaved 4K on 8 ranks: 8-9 pieces of 491 KB to and from each of 7 peers).
+    // closed, and only a successful exchange makes the lane wait for it.
     ncclResult_t first = ncclSuccess; const char* what = "";
     auto note = [&](ncclResult_t rc, const char* call) { if (rc != ncclSuccess && first == ncclSuccess) { first = rc; what = call; } };
+    uint8_t* const my_ptr = packed ? comm->pack + comm->rank * slot_bytes : frame->ptr + (size_t)mine.first * tile_row_bytes;
     for (uint32_t r = 0; r < comm->world && first == ncclSuccess; r++) {
-        pieces(r, theirs);
+        const Share sh = share(r);
+        uint8_t* const ptr = packed ? comm->pack + r * slot_bytes : frame->ptr + (size_t)sh.first * tile_row_bytes;
         if (algo == MIRHI_GATHER_BROADCAST) {
-            for (const Piece& pc : theirs) if (first == ncclSuccess) note(R->Broadcast(frame->ptr + pc.off, frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclBroadcast");
+            if (sh.bytes) note(R->Broadcast(ptr, ptr, sh.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclBroadcast");
             continue;
         }
         if (r == comm->rank) continue;
-        for (const Piece& pc : mine) if (first == ncclSuccess) note(R->Send(frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclSend");
-        for (const Piece& pc : theirs) if (first == ncclSuccess) note(R->Recv(frame->ptr + pc.off, pc.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclRecv");
+        if (mine.bytes) note(R->Send(my_ptr, mine.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclSend");
+        if (sh.bytes && first == ncclSuccess) note(R->Recv(ptr, sh.bytes, ncclUint8, (int)r, comm->comm, stream), "ncclRecv");
     }
     note(R->GroupEnd(), "ncclGroupEnd");
     if (first != ncclSuccess) return fail(MIRHI_ERR_DEVICE, "Vulkan error: RCCL: %s (%s)", R->GetErrorString(first), what);
-    HIP_TRY(hipEventRecord(comm->done, stream));             // ... and whatever follows on the lane starts behind the exchange
-    HIP_TRY(hipStreamWaitEvent(lane, comm->done, 0));
+    if (packed) for (uint32_t r = 0; r < comm->world; r++) if (r != comm->rank) HIP_TRY(strided(share(r), comm->pack + r * slot_bytes, false));
+    // ... and whatever touches the frame next waits for the exchange: a HIP lane through an event, an AQL queue through the frame's attachment record
+    // (order_attachments: the exchange stream is this image's last user)
+    HIP_TRY(hipEventRecord(comm->done, stream));
+    if (!native_after) HIP_TRY(hipStreamWaitEvent(lane, comm->done, 0));
+    { std::lock_guard<std::mutex> lk(dev->mu); frame->last_stream = stream; frame->last_native = nullptr; frame->last_cmd = nullptr; frame->last_seq = 0; }
     return MIRHI_OK;
 }
 extern "C" mirhi_result mirhi_comm_destroy(mirhi_comm* comm) {
@@ -3053,7 +3101,12 @@ extern "C" mirhi_result mirhi_comm_destroy(mirhi_comm* comm) {
     (void)sync_all_lanes(comm->dev);
     (void)hipStreamSynchronize(comm->stream);
     (void)comm->rccl->CommDestroy(comm->comm);
-    (void)hipEventDestroy(comm->ready); (void)hipEventDestroy(comm->done); (void)hipStreamDestroy(comm->stream);
+    (void)hipEventDestroy(comm->ready); (void)hipEventDestroy(comm->done);
+    { std::lock_guard<std::mutex> lk(comm->dev->mu); auto& v = comm->dev->aux_streams; v.erase(std::remove(v.begin(), v.end(), comm->stream), v.end());
+      for (mirhi_image* img : comm->dev->images) if (img->last_stream == comm->stream) img->last_stream = nullptr; }
+    (void)hipStreamDestroy(comm->stream);
+    if (comm->pack) (void)hipFree(comm->pack);
+    if (comm->seq_word) (void)hipFree(comm->seq_word);
     comm->dev->children--;
     delete comm;
     return MIRHI_OK;

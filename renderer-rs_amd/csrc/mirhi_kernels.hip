@@ -42,6 +42,10 @@ namespace mirhi {
 __device__ __attribute__((used)) char g_build_id[17] = MIRHI_SOURCE_HASH;       // (not const: a const at namespace scope is a local symbol, the loader would not find it)
 // measurement only (mirhi_device_measure_roundtrip): one wave that does nothing
 __global__ __launch_bounds__(64) void noop_kernel(uint32_t) {}
+// behind a natively dispatched frame of a tile split: tells the band-exchange stream (hipStreamWaitValue64 on signal memory) that the frame is rendered
+__global__ __launch_bounds__(64) void seq_store_kernel(uint64_t* word, uint64_t value) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host side of this translation unit)
@@ -66,6 +70,10 @@ static inline hipError_t launch_result() { const hipError_t e = t_native_err; t_
 
 hipError_t launch_noop(NativeQueue* q, uint64_t signal) {
     return native_launch(q, reinterpret_cast<const void*>(+noop_kernel), dim3(1), dim3(64), signal, NATIVE_RELEASE_SYSTEM, (uint32_t)0);
+}
+
+hipError_t launch_seq_store(NativeQueue* q, uint64_t* word, uint64_t value) {
+    return native_launch(q, reinterpret_cast<const void*>(+seq_store_kernel), dim3(1), dim3(64), 0, NATIVE_RELEASE_SYSTEM, word, value);
 }
 
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t) {

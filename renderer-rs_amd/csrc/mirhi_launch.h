@@ -37,6 +37,8 @@ hipError_t launch_fragment_count(const PassParams& P, const PassParams* dev_para
 hipError_t launch_winner_count(const uint32_t* prim, uint32_t pixels, unsigned long long* stats, hipStream_t stream);
 // measurement: one empty one-wave kernel on an AQL queue, `signal` decremented at its end (mirhi_device_measure_roundtrip)
 hipError_t launch_noop(NativeQueue* q, uint64_t signal);
+// one single-lane kernel on an AQL queue that stores `value` into `word` (signal memory, system scope): a HIP stream waits for it (hipStreamWaitValue64)
+hipError_t launch_seq_store(NativeQueue* q, uint64_t* word, uint64_t value);
 // sRGB byte -> linear table of the current device (R8G8B8A8_SRGB textures); 256 floats
 hipError_t upload_srgb_lut(const float* lut, hipStream_t stream);   // asynchronous: the caller synchronises `stream`
 }  // namespace mirhi

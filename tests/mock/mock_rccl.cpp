@@ -5,7 +5,11 @@
 // child process.  Semantics kept: point-to-point operations match in posting order per (sender, receiver) pair; a matched pair is
 // a device-to-device copy on the receiver's stream, ordered behind what the sender's stream held when it posted, and the sender's
 // stream continues behind the copy.  Not kept: a group's operations start only when the peer has posted (one thread plays all
-// ranks, so nothing may block) -- the test synchronises the device before it looks at the frames.
+// ranks, so nothing may block) -- the test synchronises the device before it looks at the frames.  Consequence for the PACKED exchange of
+// interleaved tile rows (the library scatters the received slots into the frame right behind the group): a receive whose peer posts later
+// delivers behind that scatter, so the test runs every exchange twice on unchanged frames -- the second scatter finds the first round's data
+// (real RCCL blocks the stream at the receive; a stand-in that blocked HIP streams on one another deadlocks on the runtime's four hardware
+// queues, which is how this was found).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstring>

@@ -78,6 +78,8 @@ solo = m.Device(0)
 res0 = m.SceneResources(solo, scene, m.Format.B8G8R8A8_SRGB); res0.render(); ref = res0.read()["color"].copy(); res0.destroy(); solo.destroy()
 N = 3
 devs = [m.Device(0) for _ in range(N)]
+for d in devs:
+    d.set_split_layout("bands")        # (the group handling is what is tested here; see mock_rccl.cpp on the packed exchange under this stand-in)
 uid = m.Comm.unique_id()
 comms = [m.Comm(devs[r], uid, r, N) for r in range(N)]
 ress = [m.SceneResources(devs[r], scene, m.Format.B8G8R8A8_SRGB) for r in range(N)]

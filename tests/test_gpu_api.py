@@ -926,6 +926,6 @@ def test_band_exchange_with_n_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ)
     env.pop("MIRHI_RCCL_LIBRARY", None)
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "mock", "split_exchange_check.py"), lib], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=180)
     assert p.returncode == 0, p.stdout[-3000:]
     assert p.stdout.count(": ok") == 15, p.stdout[-3000:]      # 7 exchanges x 2 layouts (bands, interleaved rows) + the failing-send case (the group is closed again, the next exchange works)
