@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=0, help="frames in one step (0 = the workload's default)")
     ap.add_argument("--split", default=None, choices=["none", "rows"], help="N > 1: rows (default) = tile-row split of one frame + "
                     "RCCL band exchange; none = alternate-frame rendering")
+    ap.add_argument("--split-layout", default="interleaved", choices=["bands", "interleaved"],
+                    help="N > 1, rows: which tile rows a rank rasterizes -- one contiguous band, or rows rank, rank + N, ... (load balance: SURVEY 8e); the "
+                         "torch.distributed fallback of the exchange needs bands")
     ap.add_argument("--gather", default="abi", choices=["abi", "torch"], help="band exchange: mirhi_comm_* (RCCL through the C ABI) or "
                     "torch.distributed.all_gather_into_tensor")
     ap.add_argument("--gather-algo", default="direct", choices=["direct", "broadcast"])
@@ -318,7 +321,8 @@ def main():
     if split:
         nfif = min(nfif, 2)
         rows = multigpu.padded_rows(scene.height, world)      # (padding is only needed by the torch all-gather, kept as the way out)
-        rig = Rig(nfif, band=(rank, world), rows=rows, per_submit=per_submit)
+        split_layout = args.split_layout if use_abi_gather else "bands"
+        rig = Rig(nfif, band=(rank, world, split_layout), rows=rows, per_submit=per_submit)
     else:
         rig = Rig(nfif, per_submit=per_submit)
     dev = rig.dev
@@ -351,6 +355,16 @@ def main():
             if comm is not None:
                 comm.destroy()
             comm, rccl_ranks = None, world
+            if split_layout != "bands":          # torch's in-place all-gather moves one contiguous band per rank
+                split_layout = "bands"
+                dev.wait_idle()
+                dev.set_tile_split(rank, world, layout="bands")
+                for sl in rig.slots:
+                    sl.record()
+    if comm is not None:
+        # the frames of the split leave the library as AQL packets on every lane (lane 0 too: nothing here relies on torch's stream order -- the exchange is the
+        # C ABI's, ordered behind each frame by the library itself; the timed region ends with wait_idle)
+        dev.set_native_dispatch(True)
     algo = m.GatherAlgo.DIRECT if args.gather_algo == "direct" else m.GatherAlgo.BROADCAST
 
     def frames():
@@ -681,7 +695,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wname}: {desc}", "triangles": tris, "width": scene.width, "height": scene.height,
                        "target_format": "B8G8R8A8_SRGB" if bpp == 4 else "R32G32B32A32_SFLOAT",
-                       "parallelism": (f"tile-row split x{world} + band exchange ({'RCCL through the C ABI, ' + args.gather_algo if comm is not None else 'torch.distributed ' + args.backend})" if split
+                       "parallelism": (f"tile-row split x{world} ({split_layout if split else ''}) + band exchange ({'RCCL through the C ABI, ' + args.gather_algo if comm is not None else 'torch.distributed ' + args.backend})" if split
                                        else (f"afr{world}" if world > 1 else "single")),
                        "frames_per_step": fps, "prewarm_seconds": args.prewarm_seconds, "frames_in_flight": nfif * per_submit, "queue_lanes": nfif, "frames_per_submit": per_submit,
                        "command_buffers": "re-recorded every frame (wait fence, reset, record, end, submit with fence: renderer.rs:367-557), native loop"

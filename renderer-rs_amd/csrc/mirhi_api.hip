@@ -279,6 +279,7 @@ int native_signal_wait(hsa_signal_t sig, uint64_t timeout_ns, mirhi::NativeDevic
         if (elapsed >= 200000ull) {
             uint64_t slice_ns = 10000000ull;
             if (timeout_ns != UINT64_MAX && timeout_ns - elapsed < slice_ns) slice_ns = timeout_ns - elapsed;
+            if (nd && nd->timeout_ns - (elapsed - progress_at) < slice_ns) slice_ns = nd->timeout_ns - (elapsed - progress_at);     // (never asleep past the deadline)
             (void)hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_EQ, 0, slice_ns * ticks_per_s / 1000000000ull + 1ull, HSA_WAIT_STATE_BLOCKED);
         }
     }

@@ -4,6 +4,7 @@ submits it with the fence.  Round 3 made that path cheap (plan cache, host-writt
 last dispatch); these tests pin that it is still the oracle's frame when the recording changes from frame to frame.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -384,3 +385,102 @@ def test_a_fence_behind_milliseconds_of_work_times_out_and_then_completes(mirhi,
     assert fence.is_signaled()
     _check(_read(res), oracle.render(scene, want_bgra8=False), "frame behind the long queue")
     res.destroy(); fence.destroy(); dev.destroy()
+
+
+def test_a_device_on_the_callers_stream_keeps_stream_order_on_lane_0():
+    """mirhi_device_create_on_stream promises that the work is issued on the caller's stream (include/mirhi.h): a producer on that stream (here torch
+    filling the wrapped vertex buffer), the submit, and a consumer on the stream (torch copying the wrapped target) need no host synchronisation in
+    between.  Lane 0 of such a device therefore stays on HIP launches -- native dispatch (AQL packets on the library's own queues, unordered against
+    the stream) is what the lanes the library makes itself get, and lane 0 only after mirhi_device_set_native_dispatch(1).  (A child process that
+    imports torch first, as bench.py does.)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.environ["MIRHI_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MIRHI_ROOT"], "tests"))
+import __graft_entry__ as ge
+mirhi = ge.load_package()
+import oracle_binding as oracle
+scenes = mirhi.scenes
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    dev = mirhi.Device(0, stream=stream.cuda_stream)
+    assert "lane 0 stays on the caller's HIP stream" in dev.dispatch_path(), dev.dispatch_path()
+    a, b = scenes.random_triangles(600, 320, 200, seed=41), scenes.random_triangles(600, 320, 200, seed=42)
+    raw = lambda s: np.ascontiguousarray(s.draws[0].vertices).view(np.uint8).reshape(-1).copy()
+    verts = torch.from_numpy(raw(a)).cuda()
+    frame = torch.zeros((a.height, a.width, 4), dtype=torch.uint8, device="cuda")
+    target = mirhi.Image(dev, a.width, a.height, mirhi.Format.B8G8R8A8_SRGB, device_ptr=frame.data_ptr())
+    res = mirhi.SceneResources(dev, a, mirhi.Format.B8G8R8A8_SRGB, color_image=target,
+                               wrap_buffers=lambda d, usage, arr: mirhi.Buffer.wrap(d, usage, verts.data_ptr(), verts.numel()))
+    dev.wait_idle()
+    n0 = dev.stats().native_dispatches
+    staged = [torch.from_numpy(raw(b)).pin_memory(), torch.from_numpy(raw(a)).pin_memory()]
+    outs = []
+    for k in range(6):                                   # alternate the two vertex sets; every step: stream copy -> submit -> stream copy, no host wait
+        verts.copy_(staged[k % 2], non_blocking=True)    # producer on the caller's stream
+        res.render()                                     # lane 0: HIP launches on that stream
+        outs.append(frame.clone())                       # consumer on the caller's stream
+    stream.synchronize()
+    assert dev.stats().native_dispatches == n0, "lane 0 of a device on the caller's stream dispatched natively without being asked to"
+    refs = [oracle.render(s, want_bgra8=True)["bgra8"].astype(np.int32) for s in (b, a)]
+    for k, out in enumerate(outs):
+        d = np.abs(out.cpu().numpy().astype(np.int32) - refs[k % 2])
+        assert d.max() <= 1, f"step {k}: the frame does not show the vertices the stream wrote just before the submit (max diff {d.max()})"
+    dev.set_native_dispatch(True)                        # opt in: the same lane now dispatches natively
+    res.render(); dev.wait_idle()
+    assert dev.stats().native_dispatches > n0
+    res.color = None
+    res.destroy(); target.destroy(); dev.destroy()
+print("STREAM ORDER OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MIRHI_ROOT=root), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "STREAM ORDER OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_a_queue_that_makes_no_progress_within_the_deadline_is_a_lost_device(tmp_path):
+    """Every wait on the library's own AQL queues is bounded (MIRHI_NATIVE_TIMEOUT_MS, default 10 s without progress of the queue's read index): on expiry
+    the device is marked lost, the fence wait fails with VulkanError (VK_ERROR_DEVICE_LOST), and so does every later submit -- a host thread never spins
+    forever on a GPU, or a tool between the library and its queue, that stopped consuming packets.  Provoked here with a 1 ms deadline and one frame of
+    ~40 ms (thousands of full-screen triangles: every tile walks the whole large-triangle list), in a child process."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["MIRHI_ROOT"])
+import numpy as np
+import __graft_entry__ as ge
+m = ge.load_package()
+S = m.scenes
+W, H, N = 1920, 1080, 6000
+tri = np.array([[-1, -1], [3, -1], [-1, 3]], dtype=np.float32)
+v = np.zeros((N * 3, 6), dtype=np.float32)
+v[:, 0:2] = np.tile(tri, (N, 1)); v[:, 2] = np.repeat(np.linspace(0.9, 0.1, N, dtype=np.float32), 3); v[:, 3:6] = 0.5
+scene = S.Scene("overdraw", W, H, [S.DrawSpec(vertices=v, stride=24, count=N * 3, cull_mode=S.CULL_NONE)])
+dev = m.Device(0)
+res = m.SceneResources(dev, scene, m.Format.B8G8R8A8_SRGB)
+f = m.Fence(dev)
+t0 = time.time(); res.render(f)
+try:
+    f.wait()
+    print("NOT LOST: the frame took", time.time() - t0)
+except m.RhiError as e:
+    print("WAIT:", e.variant, "DEVICE_LOST" in str(e))
+print("STATS lost", dev.stats().device_lost)
+try:
+    res.render()
+    print("SUBMIT accepted")
+except m.RhiError as e:
+    print("SUBMIT:", e.variant, "DEVICE_LOST" in str(e))
+time.sleep(1.0)                      # the GPU is fine and finishes the frame: nothing is freed under a running kernel
+os._exit(0)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIRHI_ROOT=root, MIRHI_NATIVE_TIMEOUT_MS="1")
+    p = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert "WAIT: VulkanError True" in p.stdout, p.stdout[-2000:]
+    assert "STATS lost 1" in p.stdout and "SUBMIT: VulkanError True" in p.stdout, p.stdout[-2000:]
+    assert "mirhi: device lost: waiting for a fence: no progress within" in p.stdout, p.stdout[-2000:]
