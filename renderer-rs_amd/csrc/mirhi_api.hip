@@ -2474,6 +2474,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
             {   // small scopes: fewer triangles per geometry wave (GeometryHead::tris_per_wave) -- the chip is mostly idle, a shorter wave is a shorter frame
                 const uint32_t geo_waves = P.total_slots / (uint32_t)GEOM_THREADS;
                 tg.tris_per_wave = native_env().geom_tpw ? (uint32_t)native_env().geom_tpw : (geo_waves <= 256u ? 16u : (geo_waves <= 512u ? 32u : 64u));
+                if (pi < c->planned.size() && c->planned[pi].draws.size() == 1u) tg.head_draw = &c->planned[pi].draws[0];      // (GeometryHead::vb0: launch_geometry decides)
             }
             // (timing may be restricted to one queue lane -- bits 8..15 of the mask hold lane + 1 -- so that the other lanes run
             // untimed: a timed dispatch completes through its own signal and does not overlap its neighbours the way an untimed one does)

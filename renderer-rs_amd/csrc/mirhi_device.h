@@ -197,6 +197,10 @@ struct PassParams {
 struct GeometryHead {
     const DrawDesc* draws; uint32_t num_draws;
     uint32_t tris_per_wave;          // triangles a 64-lane workgroup takes: 64, or 32 / 16 for small scopes (the other lanes help with the pairs)
+    // Scopes of ONE non-indexed draw of the TRIANGLE program (the reference's own frame, BASELINE configs[0] and [1]): where its vertices are, by value, so
+    // that a wave's vertex loads hang off the kernarg load alone -- beside the descriptor's scalar loads instead of behind them (0.85 us of a wave's 9).
+    // vb0 == nullptr: the descriptor says where (every other scope).
+    const uint8_t* vb0; uint32_t stride0, first0, tris0;
 };
 struct RasterHead {
     uint32_t* bin_count; const BinRec* bin_pool; uint32_t* big_count;

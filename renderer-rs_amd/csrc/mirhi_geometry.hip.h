@@ -523,6 +523,18 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
     // lanes share out among themselves (bin_triangle_pairs), take fewer rounds, and the wave's dependent chain is that much shorter.
     const uint32_t tpw = H.tris_per_wave;
     const uint32_t slot0 = blockIdx.x * tpw;
+    // One non-indexed TRIANGLE-program draw (GeometryHead::vb0): the vertices are requested here, off the kernel arguments alone -- the loads are on their
+    // way while the draw descriptor's and the parameters' scalar loads are (a scope of one draw: slot = triangle)
+    const bool head_fetch = H.vb0 != nullptr;
+    uint32_t hv[3][6];
+    if (head_fetch && threadIdx.x < tpw && slot0 + threadIdx.x < H.tris0) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            const uint8_t* v = H.vb0 + (size_t)(H.first0 + 3u * (slot0 + threadIdx.x) + k) * H.stride0;
+#pragma unroll
+            for (uint32_t w = 0; w < 6; w++) hv[k][w] = ldu(v, 4u * w);
+        }
+    }
     uint32_t lo = 0, hi = H.num_draws;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -561,7 +573,17 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
             if (threadIdx.x == 0) __hip_atomic_fetch_or(P.status, STATUS_ALPHA_TEST_TEXTURED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (has_tri && !dropped) {
+    if (has_tri && !dropped && head_fetch) {
+#pragma unroll
+        for (uint32_t k = 0; k < 3; k++) {
+            c[k] = {__uint_as_float(hv[k][0]), __uint_as_float(hv[k][1]), __uint_as_float(hv[k][2]), 1.0f};          // vertex/triangle.hlsl:19
+            if (EARLY_COLOUR && want_flat) {
+                if (k == 0) { col0[0] = hv[0][3]; col0[1] = hv[0][4]; col0[2] = hv[0][5]; }
+                else is_flat = is_flat && hv[k][3] == col0[0] && hv[k][4] == col0[1] && hv[k][5] == col0[2];
+            }
+        }
+    }
+    if (has_tri && !dropped && !head_fetch) {
 #pragma unroll
         for (uint32_t k = 0; k < 3; k++) {
             const uint32_t vidx = fetch_index(D, 3u * tri + k);
@@ -578,6 +600,8 @@ __device__ __forceinline__ void geometry_body(const PassParams* __restrict__ par
                 }
             }
         }
+    }
+    if (has_tri && !dropped) {
         GSTAMP_SYNC(5);
         const uint32_t o0 = outcode_view(c[0]), o1 = outcode_view(c[1]), o2 = outcode_view(c[2]);
         if (!(o0 & o1 & o2)) {

@@ -86,7 +86,10 @@ hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hi
     if (P.total_slots == 0) return hipSuccess;
     const uint32_t tpw = (t.tris_per_wave == 16u || t.tris_per_wave == 32u) ? t.tris_per_wave : (uint32_t)GEOM_THREADS;
     const uint32_t blocks = P.total_slots / tpw;
-    const GeometryHead H = {P.draws, P.num_draws, tpw};
+    GeometryHead H = {P.draws, P.num_draws, tpw, nullptr, 0u, 0u, 0u};
+    if (t.head_draw && P.num_draws == 1u && t.head_draw->index_type == 0u && t.head_draw->program == 0u && t.head_draw->vs_words == 0u && t.head_draw->stride >= 24u) {
+        H.vb0 = t.head_draw->vb; H.stride0 = t.head_draw->stride; H.first0 = t.head_draw->first; H.tris0 = t.head_draw->tri_count;
+    }
     // (more waves than the chip holds at five per SIMD: the occupancy-oriented variant)
     if (blocks > 5u * 1024u) MIRHI_LAUNCH(geometry_kernel<7>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
     else MIRHI_LAUNCH(geometry_kernel<5>, dim3(blocks), dim3(GEOM_THREADS), stream, t, dev_params, H);
@@ -173,7 +176,7 @@ hipError_t launch_geometry_batch(const PassParams* const* P, const PassParams* c
     uint32_t most = 0, total = 0;
     for (uint32_t i = 0; i < n; i++) {
         B.params[i] = dev_params[i];
-        B.head[i] = GeometryHead{P[i]->draws, P[i]->num_draws, (uint32_t)GEOM_THREADS};
+        B.head[i] = GeometryHead{P[i]->draws, P[i]->num_draws, (uint32_t)GEOM_THREADS, nullptr, 0u, 0u, 0u};
         B.blocks[i] = P[i]->total_slots / GEOM_THREADS;
         most = B.blocks[i] > most ? B.blocks[i] : most; total += B.blocks[i];
     }

@@ -13,8 +13,9 @@ namespace mirhi {
 // how a submit's fence is signalled (mirhi_queue_submit).
 // native: dispatch on this AQL queue instead of a HIP stream (mirhi_native.h); native_signal: an hsa_signal_t handle decremented at the
 // kernel's end (a submit's fence), 0 = none.  Never together with start / stop.
-// tris_per_wave: GeometryHead::tris_per_wave (0 = 64)
-struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; uint32_t native_flags = 0; uint32_t tris_per_wave = 0; };
+// tris_per_wave: GeometryHead::tris_per_wave (0 = 64); head_draw: the HOST copy of the scope's only draw descriptor (GeometryHead::vb0 is filled from it), or nullptr
+struct LaunchTiming { hipEvent_t start = nullptr, stop = nullptr; NativeQueue* native = nullptr; uint64_t native_signal = 0; uint32_t native_flags = 0; uint32_t tris_per_wave = 0;
+                      const DrawDesc* head_draw = nullptr; };
 hipError_t launch_vertex(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});      // no-op unless the scope uses MODEL programs
 hipError_t launch_geometry(const PassParams& P, const PassParams* dev_params, hipStream_t stream, LaunchTiming t = {});
 // big_count: the large-triangle counter of this submit's parity (dev_params carries the same pointer)
