@@ -30,6 +30,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+SIMDS, CLOCK_GHZ = 1024, 2.4     # 256 CUs x 4 SIMDs; shader clock of the issue bound below
+# cycles a SIMD needs per wave64 instruction, measured on this part (tools/microbench/valu_rate*.hip, salu_rate.hip): VALU 2.5 (add / mul / fma / logic) to 4.3
+# (v_mad_i32_i24, compares, selects, shifts, conversions); SALU 4.3; a VALU and a SALU instruction of different waves issue side by side
+VALU_CYCLES, SALU_CYCLES = (2.5, 4.3), 4.3
+
+
+def issue_bound(insts, kernel_us):
+    """roofline.issue_*: the kernel's instruction-issue bound from its measured instruction mix (committed SQ counters of the same build) --
+    max(VALU x cycles per VALU, SALU x cycles per SALU) / (SIMDs x clock), for the cheapest and the dearest VALU mix -- and the fraction of it the
+    kernel's measured duration reaches.  SURVEY 8(d): 'report VALU utilisation too: the byte floor is tiny'."""
+    if not insts or not kernel_us:
+        return None
+    valu, salu = insts.get("valu", 0), insts.get("salu", 0)
+    lo = max(valu * VALU_CYCLES[0], salu * SALU_CYCLES) / (SIMDS * CLOCK_GHZ * 1e3)
+    hi = max(valu * VALU_CYCLES[1], salu * SALU_CYCLES) / (SIMDS * CLOCK_GHZ * 1e3)
+    return {"valu_insts": valu, "salu_insts": salu, "issue_bound_us": [round(lo, 2), round(hi, 2)], "issue_frac": [round(lo / kernel_us, 3), round(hi / kernel_us, 3)],
+            "how": "wave-instructions per launch from rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of this build (profiles/*_hbm_traffic.json); bound = max(VALU x 2.5..4.3, SALU x 4.3) cycles "
+                   "/ (1024 SIMDs x 2.4 GHz); frac = bound / the kernel's isolated duration"}
 
 WORKLOADS = {
     # name: (description, scene factory, default frames per step)
@@ -639,7 +657,8 @@ def main():
                                               "traffic_structural": otraffic.get("structural_bytes") if otraffic else None,
                                               "traffic_source": onote, "algorithmic_bytes_per_launch": oalg, "avg_kernel_us": round(k_us["raster"], 3),
                                               "geometry_kernel_us": round(k_us["geometry"], 3), "vertex_kernel_us": round(k_us["vertex"], 3),
-                                              "frame_frac": round(oalg / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if fus > 0 else None}}
+                                              "frame_frac": round(oalg / (fus * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if fus > 0 else None,
+                                              "issue": issue_bound((otraffic or {}).get("instructions", {}).get("raster_kernel"), k_us["raster"])}}
                 orig.destroy()
             except Exception as e:
                 wl_out[other] = {"error": repr(e)}
@@ -719,6 +738,7 @@ def main():
                          "geometry_kernel_us": round(geo_us, 3), "vertex_kernel_us": round(vs_us, 3),
                          "frame_kernels_us": round(frame_us, 3),
                          "frame_frac": round(alg_bytes / (frame_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if frame_us > 0 else None,
+                         "issue": issue_bound((traffic or {}).get("instructions", {}).get("raster_kernel"), ras_us),
                          "timed_launches": ras_n,
                          "how": "event pair attached to every dispatch (hipExtLaunchKernelGGL start/stop events = the dispatch's begin and end on "
                                 "the GPU clock, as rocprofv3 --kernel-trace reports them; nothing subtracted); a pass of frames behind the timed "

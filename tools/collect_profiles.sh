@@ -8,7 +8,7 @@
 #   bench_*     plain bench lines (no tool attached): the driver's command, and the other BASELINE configs
 # tools/make_profile_summaries.py <tag> turns the raw CSVs into the files committed under profiles/.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
@@ -22,9 +22,16 @@ for w in c2 c3 c4 c5; do
   rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_32B_sum --output-format csv -d $out/pmc_rdreq_$w -- python3 bench.py --workload $w --profile-pass-only --no-cpu-baseline > /dev/null 2> $out/pmc_rdreq_$w.err
   echo "collected $w"
 done
-rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras > $out/bench_traced.json 2> $out/trace.err
+# the deep-queue loop (command buffers recorded once, resubmitted on four lanes) under the tracer: overlap of consecutive raster kernels
+rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras --resubmit > $out/bench_traced.json 2> $out/trace.err
+# native dispatch (hand-written AQL packets) under counter collection: the queue the library gets is a tool's proxy (mirhi_api.hip, native_queue_is_proxy); with
+# MIRHI_NATIVE_DISPATCH=2 it dispatches natively all the same -- every wait bounded (MIRHI_NATIVE_TIMEOUT_MS) -- and the frames' kernels show up on a queue of their own
+MIRHI_NATIVE_DISPATCH=2 MIRHI_NATIVE_TIMEOUT_MS=5000 timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES --output-format csv -d $out/pmc_native -- python3 bench.py --workload c2 --profile-pass-only --no-cpu-baseline > $out/bench_pmc_native.json 2> $out/pmc_native.err || echo "pmc_native run failed: rc $?"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --timeline-out $out/timeline_in_flight.json > $out/bench_default.json 2> $out/bench_default.err
 for w in c3 c4 c5; do python3 bench.py --workload $w --cpu-seconds 8 > $out/bench_$w.json 2>/dev/null; echo "bench $w done"; done
+# the tile split, every rank of world 2 / 4 / 8 in turn on this one GPU, both layouts (an emulation: tools/split_times.py)
+mkdir -p $out/summary
+python3 tools/split_times.py --json $out/summary/${tag}_split_times_one_gpu_emulation.json > $out/summary/${tag}_split_times_one_gpu_emulation.txt 2>&1 || tail -3 $out/summary/${tag}_split_times_one_gpu_emulation.txt
 # summaries are made HERE (the raw traces are too big to travel back), the bulky raw files dropped
 python3 tools/make_profile_summaries.py $tag $out/summary > $out/summary.log 2>&1 || tail -5 $out/summary.log
 find $out -name "*kernel_trace.csv" -size +2M -delete

@@ -61,6 +61,12 @@ for w in ("c2", "c3", "c4", "c5"):
                             "read_bytes_exact (the L2's read requests by size, TCC_EA0_RDREQ_{64B,128B}, and in 32-byte units to DRAM, "
                             "TCC_EA0_RDREQ_DRAM_32B: a separate pass) shows it holds for these kernels' gathers as well: the L2 fetches whole 128-byte lines",
                "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"]}
+    # the SQ instruction mix per launch (pmc_sq pass): what the issue bound of a kernel is computed from (bench.py: roofline.issue_frac)
+    for k, d in per_kernel.items():
+        if "SQ_INSTS_VALU" in d:
+            traffic.setdefault("instructions", {})[k] = {c.replace("SQ_INSTS_", "").lower(): int(round(d[c])) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM") if c in d}
+            if "SQ_WAVES" in d:
+                traffic["instructions"][k]["waves"] = int(round(d["SQ_WAVES"]))
     frame = 0
     for k, d in per_kernel.items():
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
@@ -140,3 +146,96 @@ if os.path.exists(tl):
     j = json.load(open(tl))
     j["dispatches"] = j["dispatches"][:256]
     json.dump(j, open(os.path.join(dst, f"{tag}_c2_timeline_in_flight_excerpt.json"), "w"))
+
+# ---- native dispatch under counter collection (collect_profiles.sh, pmc_native): kernels per queue, counters of the natively dispatched ones -------------
+native = None
+nat_trace = glob.glob(os.path.join(src, "pmc_native") + "/**/*kernel_trace.csv", recursive=True)
+nat_ctr = glob.glob(os.path.join(src, "pmc_native") + "/**/*counter_collection.csv", recursive=True)
+if nat_trace and nat_ctr:
+    per_queue = collections.Counter()
+    for r in csv.DictReader(open(nat_trace[0])):
+        if "mirhi::" in r["Kernel_Name"]:
+            per_queue[(r["Queue_Id"], short(r["Kernel_Name"]))] += 1
+    waves = collections.defaultdict(list)
+    for r in csv.DictReader(open(nat_ctr[0])):
+        if "mirhi::" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_WAVES":
+            waves[(r["Queue_Id"], short(r["Kernel_Name"]))].append(float(r["Counter_Value"]))
+    line = last_json(os.path.join(src, "bench_pmc_native.json")) or {}
+    native = {"command": "MIRHI_NATIVE_DISPATCH=2 rocprofv3 --kernel-trace --pmc SQ_WAVES -- python3 bench.py --workload c2 --profile-pass-only --no-cpu-baseline",
+              "dispatch_path": line.get("dispatch_path"), "completed": bool(line),
+              "dispatches_per_queue_and_kernel": {f"queue {q} {k}": n for (q, k), n in sorted(per_queue.items())},
+              "sq_waves_mean_per_queue_and_kernel": {f"queue {q} {k}": round(sum(v) / len(v), 1) for (q, k), v in sorted(waves.items())},
+              "note": "the queue with 8 geometry + 8 raster dispatches is the library's own AQL queue (the warm-up frames of the profile pass, dispatched natively through the tool's "
+                      "proxy queue); the other carries the timed pass, which launches through HIP"}
+    json.dump(native, open(os.path.join(dst, f"{tag}_c2_pmc_native_dispatch.json"), "w"), indent=1)
+
+# ---- SUMMARY: every figure quoted anywhere about this collection comes out of the files written above (no hand-copied numbers) --------------------------
+def load(name):
+    path = os.path.join(dst, name)
+    return json.load(open(path)) if os.path.exists(path) else None
+
+md = [f"# {tag}: figures of this collection (GENERATED by tools/make_profile_summaries.py from the files beside it -- do not edit)", ""]
+d = load(f"{tag}_c2_bench_default.json")
+if d:
+    md += [f"Build `{d.get('build_id')}` (matches the sources: {d.get('build_matches_sources')}); dispatch path: {d.get('dispatch_path')}.", "",
+           "## C2 driver line (`python3 bench.py --gpus 1 --steps 20 --warmup 5`)", "",
+           "| figure | value |", "|---|---|",
+           f"| headline: {d['config']['command_buffers'][:40]}..., {d['config']['frames_in_flight']} frames in flight | **{d['value']} Mtris/s** ({d['us_per_frame']} us per frame) |",
+           f"| frames verified against the oracle | {d.get('frames_verified')} (max |diff| {(d.get('verification') or {}).get('max_abs_diff')} {(d.get('verification') or {}).get('unit')}) |",
+           f"| native dispatches in the timed region | {d.get('native_dispatches')} for {d.get('frames_submitted')} frames |"]
+    rs, rr, f2 = d.get("resubmitted_submit") or {}, d.get("rerecorded_submit") or {}, d.get("frames_in_flight_2") or {}
+    md += [f"| resubmitted (recorded once, no fences) | {rs.get('value')} Mtris/s |",
+           f"| re-recorded, changing triangle count | {(rr.get('changing_triangle_count') or {}).get('value')} Mtris/s |",
+           f"| host us per frame (re-recorded loop) | {rr.get('host_us_per_frame')} |",
+           f"| 2 frames in flight, re-recorded + fenced | **{(f2.get('rerecorded') or {}).get('value')} Mtris/s** ({(f2.get('rerecorded') or {}).get('us_per_frame')} us) |",
+           f"| 2 frames in flight, resubmitted | {(f2.get('resubmitted') or {}).get('value')} Mtris/s |",
+           f"| chain of one fenced frame (us) | {json.dumps({k: v for k, v in (f2.get('chain_us') or {}).items() if k != 'how'})} |",
+           f"| batched submit (8 frames per call) | {(d.get('batched_submit') or {}).get('value')} Mtris/s |",
+           f"| shaded Mpix/s, overdraw | {d.get('shaded_mpix_per_s')}, {d.get('overdraw')} |",
+           f"| CPU oracle | {(d.get('cpu_baseline') or {}).get('value')} Mtris/s on {(d.get('cpu_baseline') or {}).get('cores')} threads, {((d.get('cpu_baseline') or {}).get('single_thread') or {}).get('value')} on one |", ""]
+    wl = d.get("workloads") or {}
+    if wl:
+        md += ["## other workloads in the same line", "", "| workload | Mtris/s (4 in flight) | re-recorded | us per frame | raster / geometry / vertex us | HBM frac (raster) |", "|---|---|---|---|---|---|"]
+        for k, v in wl.items():
+            if "error" in v:
+                md.append(f"| {k} | error: {v['error']} | | | | |"); continue
+            r = v["roofline"]
+            md.append(f"| {k} | {v['value']} | {v['rerecorded_submit']['value']} | {v['us_per_frame']} | {r['avg_kernel_us']} / {r['geometry_kernel_us']} / {r['vertex_kernel_us']} | {r['frac']} |")
+        md.append("")
+md += ["## isolated pass under rocprofv3 (`--kernel-trace --stats`, `bench.py --workload cN --profile-pass-only`) and the PMC passes", "",
+       "| workload | kernel | tracer avg us | event-pair avg us (untraced pass of the same run) | VALU / SALU wave-instructions per launch | HBM bytes per launch |", "|---|---|---|---|---|---|"]
+for w in ("c2", "c3", "c4", "c5"):
+    stats_path, tr, pp = os.path.join(dst, f"{tag}_{w}_rocprofv3_kernel_stats.csv"), load(f"{tag}_{w}_hbm_traffic.json"), load(f"{tag}_{w}_bench_profile_pass.json")
+    if not os.path.exists(stats_path):
+        continue
+    rows = {}
+    for r in csv.DictReader(open(stats_path)):
+        k = short(r.get("Name", ""))
+        if k in ("raster_kernel", "geometry_kernel", "vertex_kernel") and k not in rows:
+            rows[k] = float(r["AverageNs"]) / 1e3
+    ev = {"raster_kernel": (pp or {}).get("roofline", {}).get("avg_kernel_us"), "geometry_kernel": (pp or {}).get("roofline", {}).get("geometry_kernel_us"), "vertex_kernel": (pp or {}).get("roofline", {}).get("vertex_kernel_us")}
+    for k, us in rows.items():
+        ins = ((tr or {}).get("instructions") or {}).get(k, {})
+        md.append(f"| {w} | {k} | {us:.2f} | {ev.get(k)} | {ins.get('valu')} / {ins.get('salu')} | {((tr or {}).get(k) or {}).get('hbm_bytes_per_launch')} |")
+md.append("")
+md += ["## HBM traffic per frame (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes)", "", "| workload | frame bytes | algorithmic | x algorithmic | structural | x structural |", "|---|---|---|---|---|---|"]
+for w in ("c2", "c3", "c4", "c5"):
+    tr = load(f"{tag}_{w}_hbm_traffic.json")
+    if tr:
+        md.append(f"| {w} | {tr['frame_hbm_bytes']} | {tr['algorithmic_bytes']} | {tr['frame_over_algorithmic']} | {tr['structural_bytes']} | {tr['frame_over_structural']} |")
+md.append("")
+md += ["## C2 deep-queue loop under the tracer (`--resubmit`, 4 lanes)", "", "```json", json.dumps(summary, indent=1), "```", ""]
+if native:
+    md += ["## native dispatch under `rocprofv3 --pmc`", "", "```json", json.dumps(native, indent=1), "```", ""]
+sp = load(f"{tag}_split_times_one_gpu_emulation.json")
+if sp:
+    md += ["## tile split, per-rank kernel times EMULATED ON ONE GPU (`tools/split_times.py`; nothing here ran on more than one GPU)", "",
+           "| workload | world, layout | slowest rank kernels us | vertex / geometry / raster per rank | predicted speed-up |", "|---|---|---|---|---|"]
+    for wname, wv in sp["workloads"].items():
+        for key, e in wv["worlds"].items():
+            if key == "1":
+                md.append(f"| {wname} | 1 | {e['frame_us']} | " + " / ".join(str(e['ranks'][0][k]) for k in ('vertex', 'geometry', 'raster')) + " | 1.0 |"); continue
+            md.append(f"| {wname} | {key} | {e['slowest_rank_kernels_us']} | " + " ; ".join("/".join(str(r[k]) for k in ('vertex', 'geometry', 'raster')) for r in e['ranks']) + f" | {e['speedup_predicted']} |")
+    md.append("")
+open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(md) + "\n")
+print("wrote", f"{tag}_SUMMARY.md")
