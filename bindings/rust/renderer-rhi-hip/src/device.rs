@@ -56,6 +56,17 @@ impl Device {
     pub fn set_tile_split(&self, rank: u32, world: u32) -> RhiResult<()> {
         check(unsafe { mirhi_sys::mirhi_device_set_tile_split(self.raw, rank, world) })
     }
+    /// Which tile rows a rank of the split gets: `interleaved` (rows rank, rank + world, ...: the default) or one contiguous band.  Every rank
+    /// the same layout, before `set_tile_split` / the communicator.
+    pub fn set_tile_split_interleaved(&self, interleaved: bool) -> RhiResult<()> {
+        let layout = if interleaved { mirhi_sys::MIRHI_SPLIT_INTERLEAVED } else { mirhi_sys::MIRHI_SPLIT_BANDS };
+        check(unsafe { mirhi_sys::mirhi_device_set_tile_split_layout(self.raw, layout) })
+    }
+    /// A device made on the caller's HIP stream keeps queue lane 0 on that stream (HIP launches); `true` lets lane 0 leave the library as AQL
+    /// packets on its own ROCr queue like the other lanes (the caller then orders its stream against the frames with fences / wait_idle).
+    pub fn set_native_dispatch(&self, enable: bool) -> RhiResult<()> {
+        check(unsafe { mirhi_sys::mirhi_device_set_native_dispatch(self.raw, enable as u32) })
+    }
     /// Submit recorded command buffers in order; semaphores of `vkQueueSubmit` collapse to stream order (renderer.rs:407-424).
     pub fn submit(&self, cmds: &[&crate::CommandBuffer], fence: Option<&crate::Fence>) -> RhiResult<()> {
         let raws: Vec<*mut mirhi_sys::mirhi_cmd> = cmds.iter().map(|c| c.raw).collect();
