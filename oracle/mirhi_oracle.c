@@ -793,6 +793,11 @@ static void* band_run(void* arg) {
                 size_t idx = (size_t)y * W + (size_t)x;
                 int pass_test = d->depth_test ? depth_cmp(d->depth_compare, z, j->depth[idx]) : 1;
                 if (!pass_test) continue;
+                /* Pieces of ONE clipped triangle may overlap by a pixel after the snap to the sub-pixel grid (a sliver piece of the fan
+                 * that flips its orientation, cull mode None).  Vulkan orders fragments between primitives, not inside one, and this
+                 * restatement must not depend on the order its own clipper emits pieces in: under Always with depth write -- the one state
+                 * where the order of two fragments of a primitive would show, in the stored depth -- the nearer of them is kept. */
+                if (d->depth_test && d->depth_write && d->depth_compare == ORACLE_CMP_ALWAYS && j->prim[idx] == t->prim && !(z < j->depth[idx])) continue;
                 float src[4];
                 int have_src = 0;
                 if (j->alpha_test[t->draw]) {

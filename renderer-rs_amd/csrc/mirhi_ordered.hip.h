@@ -87,7 +87,9 @@ __device__ __forceinline__ void ordered_record(const RecRegs& r, uint32_t box, i
         const float z = __builtin_fmaf(dy, zy, __builtin_fmaf(dx, zx, z0));
         const uint32_t zk = __float_as_uint(__builtin_amdgcn_fmed3f(z, 0.0f, 1.0f)) & 0x7FFFFFFFu;
         const uint32_t dcur = ORD_STATE(0u, b);
-        const bool pass = inside && (!P.ord_depth_test || depth_passes(P.ord_depth_op, zk, dcur));
+        bool pass = inside && (!P.ord_depth_test || depth_passes(P.ord_depth_op, zk, dcur));
+        // a second fragment of the primitive that owns the pixel (overlapping clip pieces) under Always with depth write: the nearer one is kept
+        if (P.ord_depth_test && P.ord_depth_write && P.ord_depth_op == 7u && ORD_STATE(1u, b) == prim && !(zk < dcur)) pass = false;
         if (__ballot(pass) == 0ull) continue;
         const uint32_t px = px0 + (uint32_t)bx * BLOCK, py = py0 + (uint32_t)by * BLOCK;
         f4 src = {0.0f, 0.0f, 0.0f, 0.0f};

@@ -246,7 +246,9 @@ __device__ __forceinline__ void raster_record(const RecRegs& r, uint32_t box, in
                 const uint32_t pred = P.pred;
                 const bool lt = zk < st.zk[b], eq = zk == st.zk[b];
                 const bool pass = (lt && (pred & 1u)) || (eq && (pred & 2u)) || (!lt && !eq && (pred & 4u));
-                upd = inside && pass && idk < st.idk[b];
+                // Two fragments of ONE primitive at a pixel (clip pieces that overlap after the snap): only ALWAYS-with-write shows which came
+                // last, and records reach a tile in no fixed order -- the nearer one is kept, as the oracle does (a7 there).
+                upd = inside && pass && (idk < st.idk[b] || ((pred & 8u) && idk == st.idk[b] && zk < st.zk[b]));
                 if (!(pred & 8u)) zk = st.zk[b];           // only ALWAYS-with-write replaces the depth (by the winner's)
             } else {
                 if (KEYED) zk = (zk ^ P.zflip) & P.zmask;

@@ -244,3 +244,23 @@ def test_fuzz_mixed_depth_states_in_one_scope(mirhi, oracle, device, scenes, see
     with np.errstate(invalid="ignore"):      # equal infinities (feedback blend factors overflow on both sides alike) are no error
         err = np.where(a == b, 0.0, np.abs(np.where(nan, 0, a) - np.where(nan, 0, b)) / np.maximum(1.0, np.abs(np.where(nan, 0, b))))
     assert err.max() < 1e-4
+
+
+@pytest.mark.parametrize("blend", [False, True])
+def test_overlapping_pieces_of_one_clipped_triangle_under_always_with_write(mirhi, oracle, device, scenes, blend):
+    """Found by tools/soak_fuzz.py (seed 522444): two clip pieces of ONE triangle cover the same pixel, and Always-with-write stored the depth of
+    whichever record reached the tile first -- a result that changed from run to run.  Both sides now keep the nearer fragment of a primitive
+    (raster_record's predicate mode; ordered_record for the blended segment); rendered several times, every frame equals the oracle."""
+    from test_oracle_kats import overlapping_clip_pieces_scene
+    bl = (scenes.BF_SRC_ALPHA, scenes.BF_ONE_MINUS_SRC_ALPHA, 0, scenes.BF_ONE, scenes.BF_ZERO, 0, 15) if blend else None
+    scene = overlapping_clip_pieces_scene(scenes, scenes.CMP_ALWAYS, blend=bl)
+    ref = oracle.render(scene, want_bgra8=False)
+    assert (ref["prim"] == 0).sum() > 0
+    for _ in range(6):
+        res = mirhi.SceneResources(device, scene, want_prim=True, want_depth=True)
+        res.render()
+        out = res.read()
+        res.destroy()
+        assert np.array_equal(out["prim"], ref["prim"])
+        assert np.array_equal(out["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+        assert np.abs(out["color"] - ref["rgba"]).max() < 1e-4

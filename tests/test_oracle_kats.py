@@ -441,3 +441,28 @@ def test_k9_binding_default_is_trilinear(oracle, scenes):
     assert scenes.SMALL_CASES["aniso"]().draws[0].albedo_map.max_anisotropy == 16
     a, b = oracle.render(sc)["rgba"], oracle.render(scenes.SMALL_CASES["aniso"]())["rgba"]
     assert not np.array_equal(a, b)                # the receding ground is where the two filters differ
+
+
+def overlapping_clip_pieces_scene(scenes, op, write=True, blend=None, clear_depth=0.0):
+    """One triangle that crosses the near AND the far plane (found by tools/soak_fuzz.py, seed 522444, primitive 94): its clip polygon is a fan of
+    three pieces, and after the snap to the sub-pixel grid a sliver piece lies flipped over its neighbour -- pixel (183, 38) is covered twice by
+    the same primitive (cull mode None keeps both orientations)."""
+    v = np.array([[0.39559028, 0.7726351, -0.00514638, 0.5161093, 0.54139465, 0.9170683],
+                  [0.33086586, 0.6824755, 1.0311986, 0.8583772, 0.9776306, 0.608155],
+                  [0.3072718, 0.6554115, 0.8854149, 0.7304598, 0.20604184, 0.6845877]], dtype=np.float32)
+    d = scenes.DrawSpec(vertices=v, stride=24, count=3, program=scenes.PROGRAM_TRIANGLE, cull_mode=scenes.CULL_NONE,
+                        depth_test=True, depth_write=write, depth_compare=op, blend=blend)
+    return scenes.Scene(f"overlapping-clip-pieces-op{op}", 272, 45, [d], clear_color=(0.2, 0.3, 0.4, 0.5), clear_depth=clear_depth)
+
+
+def test_fragments_of_one_primitive_are_resolved_without_an_order(oracle, scenes):
+    """Overlapping pieces of one clipped triangle: Always-with-write keeps the nearer fragment (a7 of the oracle; DESIGN.md "Depth key"), so the
+    result does not depend on the order the clipper emits pieces in -- it equals what Less leaves from a far clear."""
+    less = oracle.render(overlapping_clip_pieces_scene(scenes, scenes.CMP_LESS, clear_depth=1.0), want_bgra8=False)
+    greater = oracle.render(overlapping_clip_pieces_scene(scenes, scenes.CMP_GREATER, clear_depth=0.0), want_bgra8=False)
+    always = oracle.render(overlapping_clip_pieces_scene(scenes, scenes.CMP_ALWAYS, clear_depth=0.0), want_bgra8=False)
+    cov = less["prim"] == 0
+    assert cov.sum() > 0 and np.array_equal(cov, always["prim"] == 0) and np.array_equal(cov, greater["prim"] == 0)
+    twice = cov & (less["depth"] != greater["depth"])
+    assert twice[38, 183] and twice.sum() >= 1                      # the scene does what its name says
+    assert np.array_equal(always["depth"][cov].view(np.uint32), less["depth"][cov].view(np.uint32))

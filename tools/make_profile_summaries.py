@@ -1,6 +1,12 @@
 """Turns gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the per-round files under profiles/.
 usage: make_profile_summaries.py <tag>"""
 import collections, csv, glob, json, os, shutil, sys
+# options: --workloads c2,c3 (the per-workload part for these only), --no-trace (skip the timed-region trace part), --summary-only (only rNN_SUMMARY.md, from the
+# files already in the destination): a collection may run as several gpurun calls (20 minutes each at most) whose summaries are merged here
+opts = [a for a in sys.argv[1:] if a.startswith("--")]
+sys.argv = [sys.argv[0]] + [a for a in sys.argv[1:] if not a.startswith("--")]
+only = next((o.split("=", 1)[1].split(",") for o in opts if o.startswith("--workloads=")), ["c2", "c3", "c4", "c5"])
+no_trace, summary_only = "--no-trace" in opts or "--summary-only" in opts, "--summary-only" in opts
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
@@ -36,7 +42,7 @@ def means(pass_dir):
     return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
 
 
-for w in ("c2", "c3", "c4", "c5"):
+for w in ([] if summary_only else only):
     shutil.copy(one(f"stats_{w}/**/*kernel_stats.csv"), os.path.join(dst, f"{tag}_{w}_rocprofv3_kernel_stats.csv"))
     line = last_json(os.path.join(src, f"bench_profile_pass_{w}.json"))
     json.dump(line, open(os.path.join(dst, f"{tag}_{w}_bench_profile_pass.json"), "w"), indent=1)
@@ -87,70 +93,77 @@ for w in ("c2", "c3", "c4", "c5"):
     json.dump(traffic, open(os.path.join(dst, f"{tag}_{w}_hbm_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
-json.dump(last_json(os.path.join(src, "bench_default.json")), open(os.path.join(dst, f"{tag}_c2_bench_default.json"), "w"), indent=1)
-for w in ("c3", "c4", "c5"):
-    j = last_json(os.path.join(src, f"bench_{w}.json"))
+if not summary_only and os.path.exists(os.path.join(src, "bench_default.json")):
+    json.dump(last_json(os.path.join(src, "bench_default.json")), open(os.path.join(dst, f"{tag}_c2_bench_default.json"), "w"), indent=1)
+for w in ([] if summary_only else ("c3", "c4", "c5")):
+    j = last_json(os.path.join(src, f"bench_{w}.json")) if os.path.exists(os.path.join(src, f"bench_{w}.json")) else None
     if j:
         json.dump(j, open(os.path.join(dst, f"{tag}_{w}_bench.json"), "w"), indent=1)
 
-# ---- the 4-lane timed region as the tracer sees it: overlap of consecutive raster kernels, geometry -> raster gaps ----------
-trace = one("trace/**/*kernel_trace.csv")
-rows = []
-for r in csv.DictReader(open(trace)):
-    k = short(r["Kernel_Name"])
-    if k in ("raster_kernel", "geometry_kernel"):
-        rows.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
-rows.sort(key=lambda x: x[1])
-t0 = rows[0][1]
-ras = [x for x in rows if x[0] == "raster_kernel"]
-geo = [x for x in rows if x[0] == "geometry_kernel"]
-# steady state: the middle half of the trace
-lo, hi = len(ras) // 4, 3 * len(ras) // 4
-mid = ras[lo:hi]
-period = (mid[-1][2] - mid[0][2]) / (len(mid) - 1) / 1e3
-overlap = sum(max(0, min(mid[i][2], mid[i + 1][2]) - mid[i + 1][1]) for i in range(len(mid) - 1)) / (len(mid) - 1) / 1e3
-dur_r = sum(x[2] - x[1] for x in mid) / len(mid) / 1e3
-gmid = [x for x in geo if mid[0][1] <= x[1] <= mid[-1][1]]
-dur_g = sum(x[2] - x[1] for x in gmid) / max(1, len(gmid)) / 1e3
-# union of raster-busy time / wall time in the window
-busy, cur_b, cur_e = 0, None, None
-for _, b, e, _q in mid:
-    if cur_e is None or b > cur_e:
-        if cur_e is not None:
-            busy += cur_e - cur_b
-        cur_b, cur_e = b, e
-    else:
-        cur_e = max(cur_e, e)
-busy += cur_e - cur_b
-wall = mid[-1][2] - mid[0][1]
-queues = sorted(set(x[3] for x in rows))
-summary = {
-    "command": "rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras (C2, 4 queue lanes, 512 frames per step)",
-    "raster_dispatches": len(ras), "geometry_dispatches": len(geo), "hardware_queues_seen": queues,
-    "window": f"raster dispatches {lo}..{hi} of {len(ras)} (steady state)",
-    "raster_us": round(dur_r, 3), "geometry_us": round(dur_g, 3),
-    "frame_period_us": round(period, 3), "raster_overlap_with_next_us": round(overlap, 3),
-    "raster_busy_fraction_of_wall": round(busy / wall, 4),
-    "traced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_traced.json")) or {}).get("value"),
-    "untraced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_default.json")) or {}).get("value"),
-}
-json.dump(summary, open(os.path.join(dst, f"{tag}_c2_timed_region_trace_summary.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
-with open(os.path.join(dst, f"{tag}_c2_timed_region_trace_excerpt.csv"), "w") as f:
-    cw = csv.writer(f)
-    cw.writerow(["kernel", "begin_us", "end_us", "queue"])
-    for k, b, e, q in [x for x in rows if mid[0][1] <= x[1]][:64]:
-        cw.writerow([k, round((b - t0) / 1e3, 3), round((e - t0) / 1e3, 3), q])
-tl = os.path.join(src, "timeline_in_flight.json")
-if os.path.exists(tl):
-    j = json.load(open(tl))
-    j["dispatches"] = j["dispatches"][:256]
-    json.dump(j, open(os.path.join(dst, f"{tag}_c2_timeline_in_flight_excerpt.json"), "w"))
+summary = None
+if not no_trace:
+    # ---- the 4-lane timed region as the tracer sees it: overlap of consecutive raster kernels, geometry -> raster gaps ----------
+    trace = one("trace/**/*kernel_trace.csv")
+    rows = []
+    for r in csv.DictReader(open(trace)):
+        k = short(r["Kernel_Name"])
+        if k in ("raster_kernel", "geometry_kernel"):
+            rows.append((k, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
+    rows.sort(key=lambda x: x[1])
+    t0 = rows[0][1]
+    ras = [x for x in rows if x[0] == "raster_kernel"]
+    geo = [x for x in rows if x[0] == "geometry_kernel"]
+    # steady state: the middle half of the trace
+    lo, hi = len(ras) // 4, 3 * len(ras) // 4
+    mid = ras[lo:hi]
+    period = (mid[-1][2] - mid[0][2]) / (len(mid) - 1) / 1e3
+    overlap = sum(max(0, min(mid[i][2], mid[i + 1][2]) - mid[i + 1][1]) for i in range(len(mid) - 1)) / (len(mid) - 1) / 1e3
+    dur_r = sum(x[2] - x[1] for x in mid) / len(mid) / 1e3
+    gmid = [x for x in geo if mid[0][1] <= x[1] <= mid[-1][1]]
+    dur_g = sum(x[2] - x[1] for x in gmid) / max(1, len(gmid)) / 1e3
+    # union of raster-busy time / wall time in the window
+    busy, cur_b, cur_e = 0, None, None
+    for _, b, e, _q in mid:
+        if cur_e is None or b > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_b
+            cur_b, cur_e = b, e
+        else:
+            cur_e = max(cur_e, e)
+    busy += cur_e - cur_b
+    wall = mid[-1][2] - mid[0][1]
+    queues = sorted(set(x[3] for x in rows))
+    summary = {
+        "command": "rocprofv3 --kernel-trace -- python3 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline --no-extras (C2, 4 queue lanes, 512 frames per step)",
+        "raster_dispatches": len(ras), "geometry_dispatches": len(geo), "hardware_queues_seen": queues,
+        "window": f"raster dispatches {lo}..{hi} of {len(ras)} (steady state)",
+        "raster_us": round(dur_r, 3), "geometry_us": round(dur_g, 3),
+        "frame_period_us": round(period, 3), "raster_overlap_with_next_us": round(overlap, 3),
+        "raster_busy_fraction_of_wall": round(busy / wall, 4),
+        "traced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_traced.json")) or {}).get("value"),
+        "untraced_bench_value_mtris_per_s": (last_json(os.path.join(src, "bench_default.json")) or {}).get("value"),
+    }
+    json.dump(summary, open(os.path.join(dst, f"{tag}_c2_timed_region_trace_summary.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+    with open(os.path.join(dst, f"{tag}_c2_timed_region_trace_excerpt.csv"), "w") as f:
+        cw = csv.writer(f)
+        cw.writerow(["kernel", "begin_us", "end_us", "queue"])
+        for k, b, e, q in [x for x in rows if mid[0][1] <= x[1]][:64]:
+            cw.writerow([k, round((b - t0) / 1e3, 3), round((e - t0) / 1e3, 3), q])
+    tl = os.path.join(src, "timeline_in_flight.json")
+    if os.path.exists(tl):
+        j = json.load(open(tl))
+        j["dispatches"] = j["dispatches"][:256]
+        json.dump(j, open(os.path.join(dst, f"{tag}_c2_timeline_in_flight_excerpt.json"), "w"))
+
 
 # ---- native dispatch under counter collection (collect_profiles.sh, pmc_native): kernels per queue, counters of the natively dispatched ones -------------
 native = None
-nat_trace = glob.glob(os.path.join(src, "pmc_native") + "/**/*kernel_trace.csv", recursive=True)
-nat_ctr = glob.glob(os.path.join(src, "pmc_native") + "/**/*counter_collection.csv", recursive=True)
+if summary_only:
+    native = json.load(open(os.path.join(dst, f"{tag}_c2_pmc_native_dispatch.json"))) if os.path.exists(os.path.join(dst, f"{tag}_c2_pmc_native_dispatch.json")) else None
+    summary = json.load(open(os.path.join(dst, f"{tag}_c2_timed_region_trace_summary.json"))) if os.path.exists(os.path.join(dst, f"{tag}_c2_timed_region_trace_summary.json")) else None
+nat_trace = [] if summary_only else glob.glob(os.path.join(src, "pmc_native") + "/**/*kernel_trace.csv", recursive=True)
+nat_ctr = [] if summary_only else glob.glob(os.path.join(src, "pmc_native") + "/**/*counter_collection.csv", recursive=True)
 if nat_trace and nat_ctr:
     per_queue = collections.Counter()
     for r in csv.DictReader(open(nat_trace[0])):
@@ -203,7 +216,7 @@ if d:
             md.append(f"| {k} | {v['value']} | {v['rerecorded_submit']['value']} | {v['us_per_frame']} | {r['avg_kernel_us']} / {r['geometry_kernel_us']} / {r['vertex_kernel_us']} | {r['frac']} |")
         md.append("")
 md += ["## isolated pass under rocprofv3 (`--kernel-trace --stats`, `bench.py --workload cN --profile-pass-only`) and the PMC passes", "",
-       "| workload | kernel | tracer avg us | event-pair avg us (untraced pass of the same run) | VALU / SALU wave-instructions per launch | HBM bytes per launch |", "|---|---|---|---|---|---|"]
+       "| workload | kernel | tracer avg us | event-pair avg us of the same (traced) run | VALU / SALU wave-instructions per launch | HBM bytes per launch |", "|---|---|---|---|---|---|"]
 for w in ("c2", "c3", "c4", "c5"):
     stats_path, tr, pp = os.path.join(dst, f"{tag}_{w}_rocprofv3_kernel_stats.csv"), load(f"{tag}_{w}_hbm_traffic.json"), load(f"{tag}_{w}_bench_profile_pass.json")
     if not os.path.exists(stats_path):
@@ -224,7 +237,8 @@ for w in ("c2", "c3", "c4", "c5"):
     if tr:
         md.append(f"| {w} | {tr['frame_hbm_bytes']} | {tr['algorithmic_bytes']} | {tr['frame_over_algorithmic']} | {tr['structural_bytes']} | {tr['frame_over_structural']} |")
 md.append("")
-md += ["## C2 deep-queue loop under the tracer (`--resubmit`, 4 lanes)", "", "```json", json.dumps(summary, indent=1), "```", ""]
+if summary:
+    md += ["## C2 deep-queue loop under the tracer (`--resubmit`, 4 lanes)", "", "```json", json.dumps(summary, indent=1), "```", ""]
 if native:
     md += ["## native dispatch under `rocprofv3 --pmc`", "", "```json", json.dumps(native, indent=1), "```", ""]
 sp = load(f"{tag}_split_times_one_gpu_emulation.json")
