@@ -36,6 +36,13 @@ for name, a, b in (("prologue (counters)", 0, 1), ("bin list (fill+raster)", 1, 
     d = s[:, b] - s[:, a]
     d = d[(s[:, b] > 0) & (s[:, a] > 0)]
     if len(d): print(f"  {name:32s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
+# s_memtime counts per XCD: launch ramp and drain are read inside each XCD (slot 6 = 1 + XCC_ID), then averaged over the eight
+if (s[:, 6] > 0).all():
+    ramp, span, life = [], [], []
+    for x in sorted(set(s[:, 6])):
+        sx = s[s[:, 6] == x]
+        ramp.append(us(sx[:, 0].max() - sx[:, 0].min())); span.append(us(sx[:, 4].max() - sx[:, 0].min())); life.append(us((sx[:, 4] - sx[:, 0]).mean()))
+    print(f"  per XCD ({len(ramp)} XCDs, {len(s) // max(1, len(ramp))} waves each): first wave start -> last wave start {np.mean(ramp):.2f} us (max {max(ramp):.2f}); first start -> last end {np.mean(span):.2f} us (max {max(span):.2f}); mean wave life {np.mean(life):.2f} us")
 print(f"  wave start spread: p50 {us(np.median(s[:,0]-t0)):.2f} us, max {us((s[:,0]-t0).max()):.2f} us")
 buf = np.zeros(16384 * 8, dtype=np.uint64)
 L.mirhi_debug_read_geo_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
