@@ -12,7 +12,7 @@ __device__ uint64_t g_stamps_geo[16384 * 8];
 // diagnostic only: wait for everything outstanding, then stamp (where did the time go: this changes the schedule it measures)
 #define GSTAMP_SYNC(k) do { __builtin_amdgcn_s_waitcnt(0); GSTAMP(k); } while (0)
 #define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
-    if (wv < 32768u) { g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0) g_stamps[wv * 8u + 6u] = 1u + __builtin_amdgcn_s_getreg(20 | (3 << 11)); } } } while (0)   /* slot 6: 1 + XCC_ID -- s_memtime counts per XCD */
+    if (wv < 32768u) { g_stamps[wv * 8u + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0) g_stamps[wv * 8u + 6u] = wall_clock64(); if ((k) == 4) g_stamps[wv * 8u + 7u] = wall_clock64(); } } } while (0)   /* slots 6, 7: start and end on the device-wide 100 MHz clock (s_memtime counts per compute unit group: no two waves can be compared) */
 // instruction-count attribution: the raster kernel returns after stage g_stage_limit (1 prologue, 2 fill of the first
 // chunk, 3 both lists); the SQ instruction counters of such runs, differenced, give the dynamic cost of each stage
 __device__ uint32_t g_stage_limit;

@@ -36,13 +36,12 @@ for name, a, b in (("prologue (counters)", 0, 1), ("bin list (fill+raster)", 1, 
     d = s[:, b] - s[:, a]
     d = d[(s[:, b] > 0) & (s[:, a] > 0)]
     if len(d): print(f"  {name:32s} mean {us(d.mean()):7.2f} us  p50 {us(np.median(d)):7.2f}  max {us(d.max()):7.2f}")
-# s_memtime counts per XCD: launch ramp and drain are read inside each XCD (slot 6 = 1 + XCC_ID), then averaged over the eight
-if (s[:, 6] > 0).all():
-    ramp, span, life = [], [], []
-    for x in sorted(set(s[:, 6])):
-        sx = s[s[:, 6] == x]
-        ramp.append(us(sx[:, 0].max() - sx[:, 0].min())); span.append(us(sx[:, 4].max() - sx[:, 0].min())); life.append(us((sx[:, 4] - sx[:, 0]).mean()))
-    print(f"  per XCD ({len(ramp)} XCDs, {len(s) // max(1, len(ramp))} waves each): first wave start -> last wave start {np.mean(ramp):.2f} us (max {max(ramp):.2f}); first start -> last end {np.mean(span):.2f} us (max {max(span):.2f}); mean wave life {np.mean(life):.2f} us")
+# s_memtime cannot be compared between waves; launch ramp and drain are read on the device-wide 100 MHz clock (slots 6, 7: 10 ns steps)
+if (s[:, 6] > 0).all() and (s[:, 7] > 0).all():
+    r0 = s[:, 6].min()
+    starts = (s[:, 6] - r0) / 100.0; ends = (s[:, 7] - r0) / 100.0
+    print(f"  on the device clock: first wave start -> last wave start {starts.max():.2f} us (p50 {np.median(starts):.2f}, p90 {np.percentile(starts, 90):.2f}); first start -> last end {ends.max():.2f} us; "
+          f"waves resident at once: max {max(int(((starts <= t) & (ends > t)).sum()) for t in np.linspace(0, ends.max(), 64))}")
 print(f"  wave start spread: p50 {us(np.median(s[:,0]-t0)):.2f} us, max {us((s[:,0]-t0).max()):.2f} us")
 buf = np.zeros(16384 * 8, dtype=np.uint64)
 L.mirhi_debug_read_geo_stamps(buf.ctypes.data_as(C.c_void_p), buf.size)
