@@ -8,7 +8,8 @@
 // boundaries, written to a buffer nothing else reads.  Never compiled into libmirhi.so.
 __device__ uint64_t g_stamps[32768 * 8];
 __device__ uint64_t g_stamps_geo[16384 * 8];
-#define GSTAMP(k) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 16384u) g_stamps_geo[blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ uint64_t g_stamps_geo_rt[16384 * 2];          // start and end of each geometry wave on the device-wide 100 MHz clock
+#define GSTAMP(k) do { if ((threadIdx.x & 63u) == 0 && blockIdx.x < 16384u) { g_stamps_geo[blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0) g_stamps_geo_rt[blockIdx.x * 2u] = wall_clock64(); if ((k) == 3) g_stamps_geo_rt[blockIdx.x * 2u + 1u] = wall_clock64(); } } while (0)
 // diagnostic only: wait for everything outstanding, then stamp (where did the time go: this changes the schedule it measures)
 #define GSTAMP_SYNC(k) do { __builtin_amdgcn_s_waitcnt(0); GSTAMP(k); } while (0)
 #define STAMP(k) do { if ((threadIdx.x & 63u) == 0) { const uint32_t wv = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \

@@ -245,6 +245,9 @@ extern "C" int mirhi_debug_read_stamps(uint64_t* dst, uint32_t count) {
 extern "C" int mirhi_debug_read_geo_stamps(uint64_t* dst, uint32_t count) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_geo), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
 }
+extern "C" int mirhi_debug_read_geo_clock(uint64_t* dst, uint32_t count) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps_geo_rt), (size_t)count * 8, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int mirhi_debug_set_stage_limit(uint32_t v) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stage_limit), &v, sizeof v, 0, hipMemcpyHostToDevice);
 }

@@ -51,6 +51,12 @@ tpw = int(os.environ.get("MIRHI_GEOM_TPW", "0")) or (16 if waves64 <= 256 else (
 nb = min(16384, (scene.num_triangles + tpw - 1) // tpw)
 g = g[:nb]; g = g[g[:, 3] > 0]
 print(f"geometry waves sampled {len(g)} ({tpw} triangles per wave): kernel span {us(g[:,3].max() - g[:,0].min()):.2f} us (first start -> last end), wave start spread p50 {us(np.median(g[:,0] - g[:,0].min())):.2f} max {us((g[:,0] - g[:,0].min()).max()):.2f} us")
+rt = np.zeros(16384 * 2, dtype=np.uint64)
+L.mirhi_debug_read_geo_clock(rt.ctypes.data_as(C.c_void_p), rt.size)
+rt = rt.reshape(-1, 2).astype(np.int64)[:nb]; rt = rt[(rt[:, 0] > 0) & (rt[:, 1] > 0)]
+if len(rt):
+    r0 = rt[:, 0].min()
+    print(f"  on the device clock: first wave start -> last wave start {(rt[:, 0].max() - r0) / 100.0:.2f} us (p50 {np.median(rt[:, 0] - r0) / 100.0:.2f}, p90 {np.percentile(rt[:, 0] - r0, 90) / 100.0:.2f}); first start -> last end {(rt[:, 1].max() - r0) / 100.0:.2f} us; wave life mean {(rt[:, 1] - rt[:, 0]).mean() / 100.0:.2f} max {(rt[:, 1] - rt[:, 0]).max() / 100.0:.2f} us")
 for name, a, b in (("  entry -> draw descriptor in registers", 0, 4), ("  -> indices + vertices in registers", 4, 5), ("  -> setup done", 5, 6), ("  -> flat colour stored", 6, 1),
                    ("fetch + vs + setup", 0, 1), ("  pairs enumerated, reservations issued", 1, 7), ("  -> records stored (issued)", 7, 2), ("binning (atomics + record copies)", 1, 2), ("clip", 2, 3), ("whole wave", 0, 3)):
     d = g[:, b] - g[:, a]
