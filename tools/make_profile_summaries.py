@@ -251,5 +251,15 @@ if sp:
                 md.append(f"| {wname} | 1 | {e['frame_us']} | " + " / ".join(str(e['ranks'][0][k]) for k in ('vertex', 'geometry', 'raster')) + " | 1.0 |"); continue
             md.append(f"| {wname} | {key} | {e['slowest_rank_kernels_us']} | " + " ; ".join("/".join(str(r[k]) for k in ('vertex', 'geometry', 'raster')) for r in e['ranks']) + f" | {e['speedup_predicted']} |")
     md.append("")
+    if any("rank_period_us_2_in_flight" in e for wv in sp["workloads"].values() for e in wv["worlds"].values()):
+        md += ["A rank's frame PERIOD in the reference-shaped loop (re-recorded, fenced; its next frame's vertex / geometry kernels run under this frame's raster kernel), same emulation:", "",
+               "| workload | world, layout | period per rank us, 2 in flight | 4 in flight | one GPU's period 2 / 4 in flight | predicted speed-up 2 / 4 in flight |", "|---|---|---|---|---|---|"]
+        for wname, wv in sp["workloads"].items():
+            one = wv["worlds"]["1"]
+            for key, e in wv["worlds"].items():
+                if "rank_period_us_2_in_flight" not in e: continue
+                md.append(f"| {wname} | {key} | " + " ; ".join(str(x) for x in e["rank_period_us_2_in_flight"]) + " | " + " ; ".join(str(x) for x in e["rank_period_us_4_in_flight"]) +
+                          f" | {one.get('period_us_2_in_flight')} / {one.get('period_us_4_in_flight')} | {e['speedup_predicted_2_in_flight']} / {e['speedup_predicted_4_in_flight']} |")
+        md.append("")
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(md) + "\n")
 print("wrote", f"{tag}_SUMMARY.md")
