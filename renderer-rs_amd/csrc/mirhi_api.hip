@@ -2444,8 +2444,7 @@ static mirhi_result submit_now(mirhi_device* dev, uint32_t cmd_count, mirhi_cmd*
         // MAX_FRAMES_IN_FLIGHT = 2 loop does, a loop that keeps four frames queued gets the plain / two-team variants.
         int in_flight = 1;
         for (const mirhi_cmd* o : dev->cmds) in_flight += (o != c && o->pending) ? 1 : 0;
-        static const bool wide_forced = getenv("MIRHI_RASTER_WIDE") != nullptr;          // (read once: this is the per-frame path)
-        const bool allow_wide = in_flight <= 2 || wide_forced;
+        const bool allow_wide = in_flight <= 2 || getenv("MIRHI_RASTER_WIDE") != nullptr;
         c->last_stream = use_native ? nullptr : stream; c->last_native = use_native ? nq : nullptr; c->pending = true; c->submit_seq++;
         { const mirhi_result ro = order_attachments(dev, c, stream, use_native ? nq : nullptr); if (ro != MIRHI_OK) return ro; }
         if (std::find(dev->unchecked.begin(), dev->unchecked.end(), c) == dev->unchecked.end()) dev->unchecked.push_back(c);
