@@ -484,3 +484,24 @@ os._exit(0)
     assert "WAIT: VulkanError True" in p.stdout, p.stdout[-2000:]
     assert "STATS lost 1" in p.stdout and "SUBMIT: VulkanError True" in p.stdout, p.stdout[-2000:]
     assert "mirhi: device lost: waiting for a fence: no progress within" in p.stdout, p.stdout[-2000:]
+
+
+def test_the_library_and_its_code_object_carry_the_build_of_these_sources(mirhi):
+    """round-3 verdict item 4: libmirhi.so and libmirhi_kernels.hsaco are a pair by content, not by file name -- both carry the hash of the sources they were built
+    from (mirhi_build_id; the device symbol mirhi::g_build_id is compared at native_device_open), and a device that dispatches natively has checked it."""
+    from renderer_rs_amd import build as mbuild
+    lib_id = mirhi.lib().mirhi_build_id().decode()
+    assert lib_id == mbuild.source_hash(), f"library built from {lib_id}, sources are {mbuild.source_hash()}: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+    dev = mirhi.Device(0)
+    assert dev.dispatch_path().startswith("native"), dev.dispatch_path()
+    dev.destroy()
+
+
+def test_round_trip_probe_of_a_queue_lane(mirhi):
+    """mirhi_device_measure_roundtrip (bench.py's chain_us): an empty one-wave kernel and a bare barrier packet on the lane's own AQL queue, doorbell -> host sees the
+    signal; microseconds, a handful of them on this part, and the empty kernel is not faster than the packet alone by more than noise."""
+    dev = mirhi.Device(0)
+    kernel_us, barrier_us = dev.measure_roundtrip(0, 100)
+    assert 1.0 < barrier_us < 100.0 and 1.0 < kernel_us < 100.0, (kernel_us, barrier_us)
+    assert kernel_us > 0.7 * barrier_us
+    dev.destroy()
