@@ -2324,6 +2324,8 @@ extern "C" mirhi_result mirhi_queue_submit(mirhi_device* dev, uint32_t cmd_count
         if (cmds[i]->state != CMD_EXECUTABLE) return fail(MIRHI_ERR_DEVICE, "Vulkan error: command buffer %u is not in the executable state (call end())", i);
     }
     if (fence && fence->dev != dev) return fail(MIRHI_ERR_INVALID_HANDLE, "Invalid handle: fence belongs to another device");
+    // a lost device refuses a submit here, in the caller's thread, whether or not a submit thread would have issued it (vkQueueSubmit: VK_ERROR_DEVICE_LOST)
+    if (dev->native && dev->native->lost.load(std::memory_order_acquire)) return device_lost(dev);
     constexpr uint32_t JOB_CMDS = sizeof(mirhi_device::SubmitJob::cmds) / sizeof(mirhi_cmd*);
     if (!dev->sq_on || cmd_count > JOB_CMDS) {
         drain_submits(dev);
