@@ -39,13 +39,14 @@ static void report(const char* what, double idle, std::vector<double>& v) {
     double m = 0; for (double x : v) m += x; m /= v.size();
     printf("%-64s idle %5.0f us: mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us\n", what, idle, m, v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10]);
 }
-int main() {
+int main(int argc, char** argv) {
     HK(hsa_init());
     HK(hsa_iterate_agents(pick_gpu, nullptr));
     HK(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+    if (argc > 1) { const int pr = atoi(argv[1]); HK(hsa_amd_queue_set_priority(q, (hsa_amd_queue_priority_t)pr)); printf("queue priority %d (0 low, 1 normal, 2 high)\n", pr); }
     hsa_signal_t done, gate, none{}; HK(hsa_signal_create(1, 0, nullptr, &done)); HK(hsa_signal_create(1, 0, nullptr, &gate));
     const int N = 1500;
-    for (double idle : {0.0, 10.0, 100.0}) {
+    for (double idle : {0.0, 10.0}) {
         std::vector<double> a, b, c;
         for (int i = 0; i < N; i++) {            // A
             spin(idle);
